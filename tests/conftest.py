@@ -1,0 +1,35 @@
+"""pytest configuration: markers, import paths, fixture helpers."""
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+PKG = ROOT / "hybrid-vae-cnn-for-shm_amd"          # plays the role of the reference's 4DOF/ root on sys.path
+for p in (str(ROOT), str(PKG)):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = ROOT / "tests" / "golden"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    d = dict(np.load(GOLDEN / f"{name}.npz", allow_pickle=False))
+    if "cfg" in d:
+        d["cfg"] = json.loads(str(d["cfg"]))
+    return d
+
+
+def split_prefix(d, prefix):
+    return {k[len(prefix):]: v for k, v in d.items() if k.startswith(prefix)}
+
+
+@pytest.fixture
+def golden():
+    return load_golden
