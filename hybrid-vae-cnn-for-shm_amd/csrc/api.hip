@@ -1,0 +1,405 @@
+// api.hip — C-ABI entry points (include/shm_hip.h): parameter layout, plan/workspace, forward, loss, backward.
+//
+// The launch sequence mirrors TemporalVAE.forward (reference 4DOF/Scripts/Models/temporal_vae.py:72-77) and the
+// train step of 4DOF/Scripts/03_train_vae.py:262-271; each stage is one persistent kernel per LSTM layer.
+#include <math.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace shm {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+struct LayerInst {
+    int In = 0;
+    bool in_const = false;
+    int64_t w_ih = 0, w_hh = 0, b_ih = 0, b_hh = 0;      // element offsets into the flat parameter buffer
+    size_t Wx = 0, Wh = 0, bsum = 0, WhT = 0, WxT = 0;   // byte offsets into the workspace (packed operands)
+    size_t h_seq = 0, saved = 0;
+};
+
+}  // namespace shm
+
+struct shm_vae_plan {
+    shm_vae_config cfg;
+    int B, T, training;
+    shm::LayerInst enc[2], dec[2];
+    int64_t ln_w, ln_b, mu_w, mu_b, lv_w, lv_b, l2h_w, l2h_b, out_w, out_b, n_params;
+    // workspace byte offsets
+    size_t h_last, eps, y, xhat, rstd, mu, lv, z, h0, dpre_l2h, dmu, dlv, dyx, dy, dh_last, dh0;
+    size_t recon, score, d_recon, d_mu, d_lv, dpre_seq, dx_seq, dpre_tsum, gemm_partial, colsum_scratch;
+    size_t gemm_partial_elems;
+    size_t params_copy;     // flat fp32 copy of the parameters (head / output layer read them unpacked)
+    size_t ws_bytes;
+    // call-order state
+    bool packed, fwd_saved, loss_done, drop_active;
+    uint64_t drop_seed;
+    float* recon_ptr;       // where the last forward left recon (caller buffer or workspace)
+};
+
+namespace shm {
+
+static bool config_ok(const shm_vae_config* c) {
+    if (!c) { set_error("config is NULL"); return false; }
+    if (c->hidden_dim != 32 && c->hidden_dim != 64 && c->hidden_dim != 128) {
+        set_error("hidden_dim %d unsupported (32, 64, 128)", c->hidden_dim); return false; }
+    if (c->num_layers < 1 || c->num_layers > 2) { set_error("num_layers %d unsupported (1, 2)", c->num_layers); return false; }
+    if (c->latent_dim < 1 || c->latent_dim > 32) { set_error("latent_dim %d unsupported (1..32)", c->latent_dim); return false; }
+    if (c->input_dim < 1 || c->input_dim > 16) { set_error("input_dim %d unsupported (1..16)", c->input_dim); return false; }
+    if (c->precision != SHM_PREC_F32) { set_error("precision %d not built in this version (fp32 only)", c->precision); return false; }
+    if (!(c->dropout >= 0.f && c->dropout < 1.f)) { set_error("dropout %f out of range", c->dropout); return false; }
+    return true;
+}
+
+// state_dict order of TemporalVAE (temporal_vae.py:28-49)
+static int build_layout(const shm_vae_config* c, std::vector<shm_tensor_desc>& out) {
+    const int D = c->input_dim, H = c->hidden_dim, Z = c->latent_dim, L = c->num_layers;
+    int64_t off = 0;
+    auto add = [&](const char* name, int ndim, int s0, int s1) {
+        shm_tensor_desc d;
+        memset(&d, 0, sizeof(d));
+        snprintf(d.name, sizeof(d.name), "%s", name);
+        d.offset = off; d.ndim = ndim; d.shape[0] = s0; d.shape[1] = s1;
+        off += (int64_t)s0 * (ndim > 1 ? s1 : 1);
+        // keep every tensor 16-byte aligned inside the flat buffer (vector loads in the kernels)
+        off = (off + 3) & ~(int64_t)3;
+        out.push_back(d);
+    };
+    char nm[48];
+    auto lstm = [&](const char* pre, int in0) {
+        for (int l = 0; l < L; ++l) {
+            const int in = l == 0 ? in0 : H;
+            snprintf(nm, sizeof(nm), "%s.weight_ih_l%d", pre, l); add(nm, 2, 4 * H, in);
+            snprintf(nm, sizeof(nm), "%s.weight_hh_l%d", pre, l); add(nm, 2, 4 * H, H);
+            snprintf(nm, sizeof(nm), "%s.bias_ih_l%d", pre, l); add(nm, 1, 4 * H, 0);
+            snprintf(nm, sizeof(nm), "%s.bias_hh_l%d", pre, l); add(nm, 1, 4 * H, 0);
+        }
+    };
+    lstm("encoder_lstm", D);
+    if (c->layer_norm) { add("layer_norm.weight", 1, H, 0); add("layer_norm.bias", 1, H, 0); }
+    add("fc_mu.weight", 2, Z, H); add("fc_mu.bias", 1, Z, 0);
+    add("fc_logvar.weight", 2, Z, H); add("fc_logvar.bias", 1, Z, 0);
+    add("fc_latent_to_hidden.weight", 2, H, Z); add("fc_latent_to_hidden.bias", 1, H, 0);
+    lstm("decoder_lstm", H);
+    add("output_layer.weight", 2, D, H); add("output_layer.bias", 1, D, 0);
+    return (int)off;
+}
+
+template <typename T>
+static inline T* at(void* ws, size_t off) { return reinterpret_cast<T*>(reinterpret_cast<char*>(ws) + off); }
+
+static HeadBufs head_bufs(const shm_vae_plan* p, void* ws) {
+    HeadBufs hb;
+    hb.y = at<float>(ws, p->y); hb.xhat = at<float>(ws, p->xhat); hb.rstd = at<float>(ws, p->rstd);
+    hb.mu = at<float>(ws, p->mu); hb.lv = at<float>(ws, p->lv); hb.z = at<float>(ws, p->z); hb.h0 = at<float>(ws, p->h0);
+    hb.dpre_l2h = at<float>(ws, p->dpre_l2h); hb.dmu = at<float>(ws, p->dmu); hb.dlv = at<float>(ws, p->dlv);
+    hb.dyx = at<float>(ws, p->dyx); hb.dy = at<float>(ws, p->dy); hb.dh_last = at<float>(ws, p->dh_last);
+    hb.dh0 = at<float>(ws, p->dh0);
+    return hb;
+}
+static HeadParams head_params(const shm_vae_plan* p, const float* params) {
+    HeadParams hp;
+    hp.ln_w = p->cfg.layer_norm ? params + p->ln_w : nullptr; hp.ln_b = p->cfg.layer_norm ? params + p->ln_b : nullptr;
+    hp.mu_w = params + p->mu_w; hp.mu_b = params + p->mu_b; hp.lv_w = params + p->lv_w; hp.lv_b = params + p->lv_b;
+    hp.l2h_w = params + p->l2h_w; hp.l2h_b = params + p->l2h_b;
+    return hp;
+}
+
+}  // namespace shm
+
+using namespace shm;
+
+extern "C" const char* shm_last_error(void) { return g_err; }
+extern "C" int shm_version(void) { return 1; }
+
+extern "C" int64_t shm_vae_param_count(const shm_vae_config* cfg) {
+    if (!config_ok(cfg)) return SHM_EINVAL;
+    std::vector<shm_tensor_desc> v;
+    return build_layout(cfg, v);
+}
+
+extern "C" int shm_vae_param_layout(const shm_vae_config* cfg, shm_tensor_desc* out, int max) {
+    if (!config_ok(cfg)) return SHM_EINVAL;
+    std::vector<shm_tensor_desc> v;
+    build_layout(cfg, v);
+    for (int i = 0; i < (int)v.size() && i < max && out; ++i) out[i] = v[i];
+    return (int)v.size();
+}
+
+extern "C" int shm_vae_plan_create(const shm_vae_config* cfg, int32_t B, int32_t T, int32_t training, shm_vae_plan** out) {
+    if (!config_ok(cfg)) return SHM_EINVAL;
+    SHM_REQUIRE(out != nullptr, SHM_EINVAL, "plan_create: out is NULL");
+    SHM_REQUIRE(B >= 1 && T >= 1, SHM_EINVAL, "plan_create: empty batch or window (B=%d, T=%d)", B, T);
+    SHM_REQUIRE((int64_t)B * T * 4 * cfg->hidden_dim < (int64_t)1 << 31, SHM_EINVAL, "plan_create: B*T*4H exceeds 2^31 (B=%d T=%d)", B, T);
+    shm_vae_plan* p = new (std::nothrow) shm_vae_plan();
+    SHM_REQUIRE(p != nullptr, SHM_EINVAL, "plan_create: out of host memory");
+    memset(static_cast<void*>(p), 0, sizeof(*p));
+    p->cfg = *cfg; p->B = B; p->T = T; p->training = training ? 1 : 0;
+    const int D = cfg->input_dim, H = cfg->hidden_dim, Z = cfg->latent_dim, L = cfg->num_layers;
+
+    std::vector<shm_tensor_desc> lay;
+    p->n_params = build_layout(cfg, lay);
+    auto find = [&](const char* name) -> int64_t {
+        for (auto& d : lay) if (strcmp(d.name, name) == 0) return d.offset;
+        return -1;
+    };
+    char nm[48];
+    for (int l = 0; l < L; ++l) {
+        for (int s = 0; s < 2; ++s) {
+            LayerInst& li = s == 0 ? p->enc[l] : p->dec[l];
+            const char* pre = s == 0 ? "encoder_lstm" : "decoder_lstm";
+            li.In = (l == 0 && s == 0) ? D : H;
+            li.in_const = (s == 1 && l == 0);
+            snprintf(nm, sizeof(nm), "%s.weight_ih_l%d", pre, l); li.w_ih = find(nm);
+            snprintf(nm, sizeof(nm), "%s.weight_hh_l%d", pre, l); li.w_hh = find(nm);
+            snprintf(nm, sizeof(nm), "%s.bias_ih_l%d", pre, l); li.b_ih = find(nm);
+            snprintf(nm, sizeof(nm), "%s.bias_hh_l%d", pre, l); li.b_hh = find(nm);
+        }
+    }
+    if (cfg->layer_norm) { p->ln_w = find("layer_norm.weight"); p->ln_b = find("layer_norm.bias"); }
+    p->mu_w = find("fc_mu.weight"); p->mu_b = find("fc_mu.bias");
+    p->lv_w = find("fc_logvar.weight"); p->lv_b = find("fc_logvar.bias");
+    p->l2h_w = find("fc_latent_to_hidden.weight"); p->l2h_b = find("fc_latent_to_hidden.bias");
+    p->out_w = find("output_layer.weight"); p->out_b = find("output_layer.bias");
+
+    size_t off = 0;
+    auto take = [&](size_t elems) { size_t o = off; off += (elems * sizeof(float) + 255) & ~(size_t)255; return o; };
+    const size_t tiles = (size_t)ceil_div(B, 16);
+    const size_t BT = (size_t)B * T;
+    for (int l = 0; l < L; ++l) {
+        for (int s = 0; s < 2; ++s) {
+            LayerInst& li = s == 0 ? p->enc[l] : p->dec[l];
+            li.Wx = take(fwd_pack_elems(H, li.In));
+            li.Wh = take(fwd_pack_elems(H, H));
+            li.bsum = take(4 * H);
+            li.h_seq = take(BT * H);
+            if (training) {
+                li.WhT = take(bwd_pack_elems(H, H));
+                if (l > 0) li.WxT = take(bwd_pack_elems(H, li.In));
+                li.saved = take(tiles * T * 5 * 16 * H);
+            }
+        }
+    }
+    p->params_copy = take((size_t)p->n_params);
+    p->h_last = take((size_t)B * H); p->eps = take((size_t)B * Z);
+    p->y = take((size_t)B * H); p->xhat = take((size_t)B * H); p->rstd = take(B);
+    p->mu = take((size_t)B * Z); p->lv = take((size_t)B * Z); p->z = take((size_t)B * Z); p->h0 = take((size_t)B * H);
+    p->score = take(B);
+    if (training) {
+        p->dpre_l2h = take((size_t)B * H); p->dmu = take((size_t)B * Z); p->dlv = take((size_t)B * Z);
+        p->dyx = take((size_t)B * H); p->dy = take((size_t)B * H); p->dh_last = take((size_t)B * H); p->dh0 = take((size_t)B * H);
+        p->recon = take(BT * D); p->d_recon = take(BT * D); p->d_mu = take((size_t)B * Z); p->d_lv = take((size_t)B * Z);
+        p->dpre_seq = take(BT * 4 * H); p->dx_seq = take(BT * H); p->dpre_tsum = take((size_t)B * 4 * H);
+        size_t gp = 0;
+        auto upd = [&](int R, int M, int N) { const size_t e = gemm_tn_partial_elems(R, M, N); if (e > gp) gp = e; };
+        upd((int)BT, H, D); upd((int)BT, 4 * H, H); upd((int)BT, 4 * H, D); upd(B, 4 * H, H); upd(B, H, Z); upd(B, Z, H);
+        p->gemm_partial_elems = gp;
+        p->gemm_partial = take(gp > 0 ? gp : 1);
+        size_t cs = colsum_scratch_elems((int)BT, D);
+        const size_t cs2 = colsum_scratch_elems(B, 4 * H);
+        if (cs2 > cs) cs = cs2;
+        p->colsum_scratch = take(cs);
+    }
+    p->ws_bytes = off;
+    *out = p;
+    return SHM_OK;
+}
+
+extern "C" void shm_vae_plan_destroy(shm_vae_plan* plan) { delete plan; }
+extern "C" size_t shm_vae_plan_workspace_bytes(const shm_vae_plan* plan) { return plan ? plan->ws_bytes : 0; }
+
+static int check_ws(const shm_vae_plan* p, const void* ws) {
+    SHM_REQUIRE(p != nullptr, SHM_EINVAL, "plan is NULL");
+    SHM_REQUIRE(ws != nullptr, SHM_EWORKSPACE, "workspace is NULL");
+    SHM_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255) == 0, SHM_EWORKSPACE, "workspace must be 256-byte aligned");
+    return SHM_OK;
+}
+
+extern "C" int shm_vae_pack_weights(shm_vae_plan* p, const float* params, void* ws, void* stream) {
+    int rc = check_ws(p, ws);
+    if (rc) return rc;
+    SHM_REQUIRE(params != nullptr, SHM_EINVAL, "pack_weights: params is NULL");
+    SHM_REQUIRE((reinterpret_cast<uintptr_t>(params) & 15) == 0, SHM_EINVAL, "pack_weights: params must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int H = p->cfg.hidden_dim, L = p->cfg.num_layers;
+    SHM_HIP_CHECK(hipMemcpyAsync(at<float>(ws, p->params_copy), params, sizeof(float) * p->n_params, hipMemcpyDeviceToDevice, s));
+    for (int l = 0; l < L; ++l) {
+        for (int st = 0; st < 2; ++st) {
+            const LayerInst& li = st == 0 ? p->enc[l] : p->dec[l];
+            if ((rc = launch_pack_fwd_f32(params + li.w_ih, H, li.In, at<float>(ws, li.Wx), s))) return rc;
+            if ((rc = launch_pack_fwd_f32(params + li.w_hh, H, H, at<float>(ws, li.Wh), s))) return rc;
+            if ((rc = launch_bias_sum(params + li.b_ih, params + li.b_hh, 4 * H, at<float>(ws, li.bsum), s))) return rc;
+            if (p->training) {
+                if ((rc = launch_pack_bwd_f32(params + li.w_hh, H, H, at<float>(ws, li.WhT), s))) return rc;
+                if (l > 0 && (rc = launch_pack_bwd_f32(params + li.w_ih, H, li.In, at<float>(ws, li.WxT), s))) return rc;
+            }
+        }
+    }
+    p->packed = true;
+    return SHM_OK;
+}
+
+extern "C" int shm_vae_forward(shm_vae_plan* p, const float* x, const float* eps, float* recon, float* mu, float* logvar,
+                               float* score, int32_t train_mode, uint64_t drop_seed, void* ws, void* stream) {
+    int rc = check_ws(p, ws);
+    if (rc) return rc;
+    SHM_REQUIRE(p->packed, SHM_ESTATE, "forward: call shm_vae_pack_weights first");
+    SHM_REQUIRE(x && eps, SHM_EINVAL, "forward: x or eps is NULL");
+    hipStream_t s = (hipStream_t)stream;
+    const shm_vae_config& c = p->cfg;
+    const int B = p->B, T = p->T, D = c.input_dim, H = c.hidden_dim, Z = c.latent_dim, L = c.num_layers;
+    const bool save = p->training != 0;
+    const float drop = (train_mode && L > 1) ? c.dropout : 0.f;
+    p->drop_active = drop > 0.f; p->drop_seed = drop_seed;
+    p->fwd_saved = false; p->loss_done = false;
+
+    SHM_HIP_CHECK(hipMemcpyAsync(at<float>(ws, p->eps), eps, sizeof(float) * B * Z, hipMemcpyDeviceToDevice, s));
+
+    auto run_stack = [&](LayerInst* st, const float* in0, uint32_t stack, float* h_last) -> int {
+        for (int l = 0; l < L; ++l) {
+            LstmFwdArgs a;
+            memset(&a, 0, sizeof(a));
+            a.in = l == 0 ? in0 : at<float>(ws, st[l - 1].h_seq);
+            a.Wx = at<float>(ws, st[l].Wx); a.Wh = at<float>(ws, st[l].Wh); a.bias = at<float>(ws, st[l].bsum);
+            a.h_seq = at<float>(ws, st[l].h_seq);
+            a.h_last = (l == L - 1) ? h_last : nullptr;
+            a.saved = save ? at<float>(ws, st[l].saved) : nullptr;
+            a.B = B; a.T = T; a.In = st[l].In; a.in_const = st[l].in_const ? 1 : 0;
+            a.drop_p = l > 0 ? drop : 0.f; a.drop_seed = drop_seed; a.drop_stack = stack;
+            int r = launch_lstm_fwd_f32(H, a, s);
+            if (r) return r;
+        }
+        return SHM_OK;
+    };
+    const float* prm = at<float>(ws, p->params_copy);
+    if ((rc = run_stack(p->enc, x, 0, at<float>(ws, p->h_last)))) return rc;
+    if ((rc = launch_head_fwd(B, H, Z, c.layer_norm, at<float>(ws, p->h_last), at<float>(ws, p->eps), head_params(p, prm),
+                              head_bufs(p, ws), mu, logvar, s))) return rc;
+    if ((rc = run_stack(p->dec, at<float>(ws, p->h0), 1, nullptr))) return rc;
+    float* rec = recon ? recon : (p->training ? at<float>(ws, p->recon) : nullptr);
+    if ((rc = launch_out_fwd(B, T, D, H, at<float>(ws, p->dec[L - 1].h_seq), prm + p->out_w, prm + p->out_b, x, rec,
+                             at<float>(ws, p->score), s))) return rc;
+    if (score) SHM_HIP_CHECK(hipMemcpyAsync(score, at<float>(ws, p->score), sizeof(float) * B, hipMemcpyDeviceToDevice, s));
+    p->recon_ptr = rec;
+    p->fwd_saved = save;
+    return SHM_OK;
+}
+
+extern "C" int shm_vae_loss(shm_vae_plan* p, const float* x, float kl_w, float* losses, void* ws, void* stream) {
+    int rc = check_ws(p, ws);
+    if (rc) return rc;
+    SHM_REQUIRE(p->training && p->fwd_saved && p->recon_ptr, SHM_ESTATE, "loss: needs a forward on a training plan first");
+    SHM_REQUIRE(x && losses, SHM_EINVAL, "loss: x or losses is NULL");
+    const shm_vae_config& c = p->cfg;
+    if ((rc = launch_vae_loss(p->B, p->T, c.input_dim, c.latent_dim, x, p->recon_ptr, at<float>(ws, p->mu), at<float>(ws, p->lv),
+                              kl_w, at<float>(ws, p->d_recon), at<float>(ws, p->d_mu), at<float>(ws, p->d_lv),
+                              at<float>(ws, p->score), losses, (hipStream_t)stream))) return rc;
+    p->loss_done = true;
+    return SHM_OK;
+}
+
+extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_recon, const float* d_mu, const float* d_logvar,
+                                float* grads, void* ws, void* stream) {
+    int rc = check_ws(p, ws);
+    if (rc) return rc;
+    SHM_REQUIRE(p->training && p->fwd_saved, SHM_ESTATE, "backward: needs a forward on a training plan first");
+    SHM_REQUIRE(x && grads, SHM_EINVAL, "backward: x or grads is NULL");
+    const bool own = !d_recon && !d_mu && !d_logvar;
+    SHM_REQUIRE(own || (d_recon && d_mu && d_logvar), SHM_EINVAL, "backward: pass all three upstream gradients or none");
+    SHM_REQUIRE(!own || p->loss_done, SHM_ESTATE, "backward: no upstream gradients and shm_vae_loss was not called");
+    if (own) { d_recon = at<float>(ws, p->d_recon); d_mu = at<float>(ws, p->d_mu); d_logvar = at<float>(ws, p->d_lv); }
+    hipStream_t s = (hipStream_t)stream;
+    const shm_vae_config& c = p->cfg;
+    const int B = p->B, T = p->T, D = c.input_dim, H = c.hidden_dim, Z = c.latent_dim, L = c.num_layers;
+    const int BT = B * T, G = 4 * H;
+    const float drop = p->drop_active ? c.dropout : 0.f;
+    const float* prm = at<float>(ws, p->params_copy);
+    float* dpre_seq = at<float>(ws, p->dpre_seq);
+    float* dx_seq = at<float>(ws, p->dx_seq);
+    float* dpre_tsum = at<float>(ws, p->dpre_tsum);
+    float* cs = at<float>(ws, p->colsum_scratch);
+    const HeadBufs hb = head_bufs(p, ws);
+
+    auto gemm = [&](const float* A, int lda, int M, const float* Bm, int ldb, int N, int R, float* C, int shift_T, int trans_out,
+                    float dp, uint32_t stack) -> int {
+        GemmTnArgs g;
+        memset(&g, 0, sizeof(g));
+        g.A = A; g.lda = lda; g.Bm = Bm; g.ldb = ldb; g.C = C; g.ldc = trans_out ? M : N; g.R = R; g.M = M; g.N = N;
+        g.shift_T = shift_T; g.trans_out = trans_out; g.drop_p = dp; g.drop_seed = p->drop_seed; g.drop_stack = stack;
+        g.partial = at<float>(ws, p->gemm_partial); g.partial_elems = p->gemm_partial_elems;
+        return launch_gemm_tn_f32(g, s);
+    };
+
+    // output layer (temporal_vae.py:70): dW_out[d][k] = sum_r d_recon[r][d] h[r][k]
+    const float* h_top = at<float>(ws, p->dec[L - 1].h_seq);
+    if ((rc = gemm(h_top, H, H, d_recon, D, D, BT, grads + p->out_w, 0, 1, 0.f, 0))) return rc;
+    if ((rc = launch_colsum(d_recon, D, BT, D, grads + p->out_b, nullptr, cs, s))) return rc;
+
+    auto run_stack_bwd = [&](LayerInst* st, uint32_t stack, const float* x0, bool is_dec) -> int {
+        for (int l = L - 1; l >= 0; --l) {
+            LstmBwdArgs a;
+            memset(&a, 0, sizeof(a));
+            a.saved = at<float>(ws, st[l].saved);
+            if (l == L - 1) {
+                if (is_dec) { a.dy = d_recon; a.Wout = prm + p->out_w; a.Dy = D; }
+                else a.dh_last = hb.dh_last;
+            } else {
+                a.dh_seq = dx_seq;
+            }
+            a.WhT = at<float>(ws, st[l].WhT);
+            a.need_dx = l > 0 ? 1 : 0;
+            a.WxT = l > 0 ? at<float>(ws, st[l].WxT) : nullptr;
+            a.dpre_seq = dpre_seq; a.dpre_tsum = dpre_tsum; a.dx_seq = dx_seq;
+            a.B = B; a.T = T; a.In = st[l].In;
+            a.drop_p = l > 0 ? drop : 0.f; a.drop_seed = p->drop_seed; a.drop_stack = stack;
+            int r = launch_lstm_bwd_f32(H, a, s);
+            if (r) return r;
+            // deferred weight gradients of this layer
+            if ((r = gemm(dpre_seq, G, G, at<float>(ws, st[l].h_seq), H, H, BT, grads + st[l].w_hh, T, 0, 0.f, 0))) return r;
+            if (l > 0) {
+                if ((r = gemm(dpre_seq, G, G, at<float>(ws, st[l - 1].h_seq), H, H, BT, grads + st[l].w_ih, 0, 0, drop, stack))) return r;
+            } else if (st[l].in_const) {
+                if ((r = gemm(dpre_tsum, G, G, hb.h0, H, H, B, grads + st[l].w_ih, 0, 0, 0.f, 0))) return r;
+            } else {
+                if ((r = gemm(dpre_seq, G, G, x0, D, D, BT, grads + st[l].w_ih, 0, 0, 0.f, 0))) return r;
+            }
+            if ((r = launch_colsum(dpre_tsum, G, B, G, grads + st[l].b_ih, grads + st[l].b_hh, cs, s))) return r;
+        }
+        return SHM_OK;
+    };
+
+    if ((rc = run_stack_bwd(p->dec, 1, nullptr, true))) return rc;
+
+    // head: dpre_tsum still holds sum_t dpre of decoder layer 0
+    if ((rc = launch_head_bwd(B, H, Z, c.layer_norm, dpre_tsum, prm + p->dec[0].w_ih, at<float>(ws, p->eps), d_mu, d_logvar,
+                              head_params(p, prm), hb, s))) return rc;
+    if ((rc = gemm(hb.dpre_l2h, H, H, hb.z, Z, Z, B, grads + p->l2h_w, 0, 0, 0.f, 0))) return rc;
+    if ((rc = launch_colsum(hb.dpre_l2h, H, B, H, grads + p->l2h_b, nullptr, cs, s))) return rc;
+    if ((rc = gemm(hb.dmu, Z, Z, hb.y, H, H, B, grads + p->mu_w, 0, 0, 0.f, 0))) return rc;
+    if ((rc = launch_colsum(hb.dmu, Z, B, Z, grads + p->mu_b, nullptr, cs, s))) return rc;
+    if ((rc = gemm(hb.dlv, Z, Z, hb.y, H, H, B, grads + p->lv_w, 0, 0, 0.f, 0))) return rc;
+    if ((rc = launch_colsum(hb.dlv, Z, B, Z, grads + p->lv_b, nullptr, cs, s))) return rc;
+    if (c.layer_norm) {
+        if ((rc = launch_colsum(hb.dyx, H, B, H, grads + p->ln_w, nullptr, cs, s))) return rc;
+        if ((rc = launch_colsum(hb.dy, H, B, H, grads + p->ln_b, nullptr, cs, s))) return rc;
+    }
+
+    if ((rc = run_stack_bwd(p->enc, 0, x, false))) return rc;
+    return SHM_OK;
+}
+
+extern "C" void shm_dropout_keep_mask(uint64_t drop_seed, int32_t stack, int32_t B, int32_t T, int32_t H, float p, uint8_t* keep) {
+    const uint32_t thr = drop_threshold(p);
+    const size_t n = (size_t)B * T * H;
+    for (size_t i = 0; i < n; ++i) keep[i] = drop_hash(drop_seed, (uint32_t)stack, (uint32_t)i) >= thr ? 1 : 0;
+}

@@ -1,0 +1,85 @@
+// common.hpp — shared device/host helpers for the gfx950 LSTM-VAE kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/shm_hip.h"
+
+namespace shm {
+
+// ---------------------------------------------------------------- error plumbing
+void set_error(const char* fmt, ...);
+
+#define SHM_HIP_CHECK(expr)                                                               \
+    do {                                                                                  \
+        hipError_t e__ = (expr);                                                          \
+        if (e__ != hipSuccess) {                                                          \
+            shm::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return (int)e__;                                                              \
+        }                                                                                 \
+    } while (0)
+
+#define SHM_REQUIRE(cond, code, ...)                                                      \
+    do {                                                                                  \
+        if (!(cond)) { shm::set_error(__VA_ARGS__); return (code); }                      \
+    } while (0)
+
+#define SHM_LAUNCH_CHECK() SHM_HIP_CHECK(hipGetLastError())
+
+// ---------------------------------------------------------------- MFMA wrappers (gfx950)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+// D[16x16] += A[16x4] * B[4x16], exact f32 (v_mfma_f32_16x16x4_f32).
+// lane l supplies A[row = l&15][k = l>>4] and B[k = l>>4][col = l&15]; holds D[row = 4*(l>>4)+r][col = l&15], r = 0..3.
+__device__ __forceinline__ f32x4 mfma_f32_16x16x4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+// D[16x16] += A[16x32] * B[32x16], bf16 in / f32 accumulate (v_mfma_f32_16x16x32_bf16).
+// lane l supplies A[row = l&15][k = 8*(l>>4)+e] and B[k = 8*(l>>4)+e][col = l&15], e = 0..7; D as above.
+__device__ __forceinline__ f32x4 mfma_bf16_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {   // round-to-nearest-even; NaN stays NaN
+    unsigned int u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
+
+// ---------------------------------------------------------------- activation math
+// Parity path (fp32): ocml expf/tanhf and IEEE division.
+__device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float tanh_acc(float x) { return tanhf(x); }
+// Throughput path (bf16 operands): v_exp_f32 / v_rcp_f32 hardware approximations (~1 ulp each).
+__device__ __forceinline__ float sigmoid_fast(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float tanh_fast(float x) {
+    // tanh(x) = 1 - 2/(1+exp(2x)); saturates cleanly for |x| large (exp2 -> inf or 0)
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+}
+
+// ---------------------------------------------------------------- dropout counter RNG
+// keep-decision for element idx of stream (seed, stack); identical on host (shm_dropout_keep_mask) and device.
+__host__ __device__ __forceinline__ uint32_t drop_hash(uint64_t seed, uint32_t stack, uint32_t idx) {
+    uint32_t x = idx * 0x9E3779B1u ^ (uint32_t)seed;
+    x ^= x >> 16; x *= 0x85EBCA6Bu;
+    x ^= (uint32_t)(seed >> 32) + stack * 0x632BE5ABu;
+    x ^= x >> 13; x *= 0xC2B2AE35u;
+    x ^= x >> 16; x *= 0x27D4EB2Fu;
+    x ^= x >> 15;
+    return x;
+}
+__host__ __device__ __forceinline__ uint32_t drop_threshold(float p) {   // keep iff hash >= threshold
+    double t = (double)p * 4294967296.0;
+    return t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+}
+
+__host__ __device__ __forceinline__ int ceil_div(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ __forceinline__ int round_up(int a, int b) { return ceil_div(a, b) * b; }
+
+}  // namespace shm

@@ -1,0 +1,93 @@
+// kernels.hpp — internal launcher interface between api.hip and the kernel translation units.
+#pragma once
+#include "common.hpp"
+
+namespace shm {
+
+// ---- packed-weight geometry (fp32 MFMA 16x16x4 path) -------------------------------------------------
+// Forward operand  W[4H][K]:  Kpad = round_up(K,16), KQ = Kpad/4 (k-range owned by one lane quarter), S4 = KQ/4.
+//   packed[((ht*S4 + s4)*4 + g)*64 + lane][e] = W[g*H + ht*16 + (lane&15)][(lane>>4)*KQ + 4*s4 + e]   (0 beyond K)
+// Backward operand W^T (out[m] = sum_k W[k][m] dpre[k], k over 4H): KQ = H, S4 = H/4, MT = ceil(M/16)
+//   packed[(mt*S4 + s4)*64 + lane][e] = W[(lane>>4)*H + 4*s4 + e][mt*16 + (lane&15)]                  (0 beyond M)
+inline int fwd_kpad(int K) { return round_up(K, 16); }
+inline size_t fwd_pack_elems(int H, int K) { return (size_t)4 * H * fwd_kpad(K); }
+inline size_t bwd_pack_elems(int H, int M) { return (size_t)round_up(M, 16) * 4 * H; }
+
+struct LstmFwdArgs {
+    const float* in;        // [B,T,In] (or [B,In] when in_const)
+    const float* Wx;        // packed forward operand of W_ih
+    const float* Wh;        // packed forward operand of W_hh
+    const float* bias;      // [4H] = b_ih + b_hh
+    float* h_seq;           // [B,T,H] or nullptr
+    float* h_last;          // [B,H] or nullptr
+    float* saved;           // fragment-order [tile][T][5][H/16][64][4] (i,f,g,o,c) or nullptr
+    int B, T, In, in_const;
+    float drop_p;           // dropout on the INPUT sequence (nn.LSTM inter-layer dropout), 0 = off
+    uint64_t drop_seed;
+    uint32_t drop_stack;
+};
+int launch_lstm_fwd_f32(int H, const LstmFwdArgs& a, hipStream_t s);
+
+struct LstmBwdArgs {
+    const float* saved;     // as written by the forward
+    const float* dh_seq;    // [B,T,H] gradient arriving on h_t from the layer above, or nullptr
+    const float* dy;        // [B,T,Dy] gradient on the output layer (top decoder layer), or nullptr
+    const float* Wout;      // [Dy,H] output_layer.weight (with dy)
+    const float* dh_last;   // [B,H] extra gradient on h_{T-1} (encoder top layer), or nullptr
+    const float* WhT;       // packed backward operand of W_hh
+    const float* WxT;       // packed backward operand of W_ih (need_dx) or nullptr
+    float* dpre_seq;        // [B,T,4H] pre-activation gradients (for the deferred weight-gradient GEMMs)
+    float* dpre_tsum;       // [B,4H]  sum over t of dpre (bias gradient / const-input layer)
+    float* dx_seq;          // [B,T,In] gradient w.r.t. the layer input (need_dx), dropout mask applied
+    int B, T, In, Dy, need_dx;
+    float drop_p; uint64_t drop_seed; uint32_t drop_stack;   // mask of the layer INPUT (same stream as forward)
+};
+int launch_lstm_bwd_f32(int H, const LstmBwdArgs& a, hipStream_t s);
+
+// ---- head (LayerNorm, fc_mu, fc_logvar, reparameterise, fc_latent_to_hidden + tanh) ---------------------
+struct HeadBufs {           // all [B, *] fp32, workspace
+    float *y, *xhat, *rstd, *mu, *lv, *z, *h0;
+    float *dpre_l2h, *dmu, *dlv, *dyx, *dy, *dh_last, *dh0;
+};
+struct HeadParams {
+    const float *ln_w, *ln_b, *mu_w, *mu_b, *lv_w, *lv_b, *l2h_w, *l2h_b;
+};
+int launch_head_fwd(int B, int H, int Z, int layer_norm, const float* h_last, const float* eps, const HeadParams& p,
+                    const HeadBufs& hb, float* mu_out, float* lv_out, hipStream_t s);
+// dh0 = dpre_tsum[B,4H] . W_ih_dec0[4H,H]; then back through the head; d_mu/d_lv: upstream grads [B,Z]
+int launch_head_bwd(int B, int H, int Z, int layer_norm, const float* dpre_tsum, const float* W_ih_dec0,
+                    const float* eps, const float* d_mu, const float* d_lv, const HeadParams& p, const HeadBufs& hb,
+                    hipStream_t s);
+
+// ---- output layer + per-window score; loss --------------------------------------------------------------
+int launch_out_fwd(int B, int T, int D, int H, const float* h_seq, const float* Wout, const float* bout,
+                   const float* x, float* recon, float* score, hipStream_t s);
+int launch_vae_loss(int B, int T, int D, int Z, const float* x, const float* recon, const float* mu, const float* lv,
+                    float kl_w, float* d_recon, float* d_mu, float* d_lv, float* score, float* losses, hipStream_t s);
+
+// ---- C[M,N] (+)= sum_r A[r,M]^T B[r,N]  (weight gradients), fp32 MFMA, deterministic split-K ----------------
+struct GemmTnArgs {
+    const float* A; int lda;       // [R, M]
+    const float* Bm; int ldb;      // [R, N]
+    float* C; int ldc;             // [M, N] row-major (or transposed when trans_out)
+    int R, M, N;
+    int shift_T;                   // >0: B row r is taken from row r-1, zero when r % shift_T == 0  (h_{t-1})
+    int trans_out;                 // write C[n*ldc + m]
+    float drop_p; uint64_t drop_seed; uint32_t drop_stack;   // dropout mask applied to B elements (idx = r*N + n)
+    float* partial;                // split-K scratch
+    size_t partial_elems;
+};
+int launch_gemm_tn_f32(const GemmTnArgs& a, hipStream_t s);
+size_t gemm_tn_partial_elems(int R, int M, int N);
+// out[n] = sum_r A[r*lda + n], written to out0 and (if non-null) out1; scratch: colsum_scratch_elems(R,N) floats
+int launch_colsum(const float* A, int lda, int R, int N, float* out0, float* out1, float* scratch, hipStream_t s);
+size_t colsum_scratch_elems(int R, int N);
+// out[i] (and out1[i]) = sum_p partial[p*n + i], p < nparts (fixed order)
+int launch_reduce_partials(const float* partial, int nparts, size_t n, float* out0, float* out1, hipStream_t s);
+
+// ---- weight packing -----------------------------------------------------------------------------------------
+int launch_pack_fwd_f32(const float* W, int H, int K, float* dst, hipStream_t s);
+int launch_pack_bwd_f32(const float* W, int H, int M, float* dst, hipStream_t s);
+int launch_bias_sum(const float* b_ih, const float* b_hh, int n, float* dst, hipStream_t s);
+
+}  // namespace shm

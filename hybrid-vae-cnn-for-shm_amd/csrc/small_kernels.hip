@@ -1,0 +1,351 @@
+// small_kernels.hip — the latency-trivial pieces around the LSTM recurrences (gfx950, wave64):
+//   head_fwd / head_bwd : LayerNorm -> fc_mu, fc_logvar -> reparameterise -> tanh(fc_latent_to_hidden)
+//                         (reference 4DOF/Scripts/Models/temporal_vae.py:55-57, 60-63, 67) and its backward
+//   out_fwd             : output_layer (temporal_vae.py:70) + per-window score (04_vae_thresholding.py:122)
+//   vae_loss            : recon/KL/total loss and their gradients (03_train_vae.py:264-266)
+//   colsum, pack_*      : bias gradients; MFMA fragment-order weight packing (layouts in kernels.hpp)
+// One wave per window row; reductions are wave shuffles in a fixed order (bitwise reproducible).
+#include "kernels.hpp"
+
+namespace shm {
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+constexpr int HMAX = 128;   // hidden_dim limit of the head kernels
+constexpr int ZMAX = 32;    // latent_dim limit
+
+// ------------------------------------------------------------------------------------------------ head forward
+__global__ void __launch_bounds__(256) head_fwd_kernel(int B, int H, int Z, int layer_norm, const float* __restrict__ h_last,
+                                                       const float* __restrict__ eps, HeadParams p, HeadBufs hb,
+                                                       float* mu_out, float* lv_out) {
+    __shared__ float ys[4][HMAX];
+    __shared__ float zs[4][ZMAX];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row_raw = blockIdx.x * 4 + w;
+    const bool valid = row_raw < B;
+    const int row = valid ? row_raw : B - 1;
+    const float* h = h_last + (size_t)row * H;
+
+    float hv[HMAX / 64], s = 0.f;
+#pragma unroll
+    for (int i = 0; i < HMAX / 64; ++i) { const int k = lane + 64 * i; hv[i] = k < H ? h[k] : 0.f; s += hv[i]; }
+    if (layer_norm) {
+        const float mean = wave_sum(s) / (float)H;
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < HMAX / 64; ++i) { const int k = lane + 64 * i; const float d = k < H ? hv[i] - mean : 0.f; v += d * d; }
+        const float var = wave_sum(v) / (float)H;           // biased variance (nn.LayerNorm)
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < HMAX / 64; ++i) {
+            const int k = lane + 64 * i;
+            if (k < H) {
+                const float xh = (hv[i] - mean) * rstd;
+                const float y = xh * p.ln_w[k] + p.ln_b[k];
+                ys[w][k] = y;
+                if (valid) { hb.xhat[(size_t)row * H + k] = xh; hb.y[(size_t)row * H + k] = y; }
+            }
+        }
+        if (valid && lane == 0) hb.rstd[row] = rstd;
+    } else {
+#pragma unroll
+        for (int i = 0; i < HMAX / 64; ++i) {
+            const int k = lane + 64 * i;
+            if (k < H) { ys[w][k] = hv[i]; if (valid) hb.y[(size_t)row * H + k] = hv[i]; }
+        }
+    }
+    __syncthreads();
+    if (lane < Z) {
+        float m = p.mu_b[lane], l = p.lv_b[lane];
+        const float* wm = p.mu_w + (size_t)lane * H;
+        const float* wl = p.lv_w + (size_t)lane * H;
+        for (int k = 0; k < H; ++k) { const float y = ys[w][k]; m = fmaf(y, wm[k], m); l = fmaf(y, wl[k], l); }
+        const float sd = expf(0.5f * l);
+        const float z = m + eps[(size_t)row * Z + lane] * sd;
+        zs[w][lane] = z;
+        if (valid) {
+            hb.mu[(size_t)row * Z + lane] = m; hb.lv[(size_t)row * Z + lane] = l; hb.z[(size_t)row * Z + lane] = z;
+            if (mu_out) mu_out[(size_t)row * Z + lane] = m;
+            if (lv_out) lv_out[(size_t)row * Z + lane] = l;
+        }
+    }
+    __syncthreads();
+    for (int k = lane; k < H; k += 64) {
+        float acc = p.l2h_b[k];
+        const float* wr = p.l2h_w + (size_t)k * Z;
+        for (int z = 0; z < Z; ++z) acc = fmaf(zs[w][z], wr[z], acc);
+        if (valid) hb.h0[(size_t)row * H + k] = tanhf(acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ head backward
+__global__ void __launch_bounds__(256) head_bwd_kernel(int B, int H, int Z, int layer_norm, const float* __restrict__ dpre_tsum,
+                                                       const float* __restrict__ W_ih_dec0, const float* __restrict__ eps,
+                                                       const float* __restrict__ d_mu, const float* __restrict__ d_lv,
+                                                       HeadParams p, HeadBufs hb) {
+    __shared__ float ds[4][4 * HMAX];    // dpre_tsum row
+    __shared__ float dl[4][HMAX];        // d(pre-tanh) of fc_latent_to_hidden
+    __shared__ float dmz[4][2 * ZMAX];   // dmu | dlv
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row_raw = blockIdx.x * 4 + w;
+    const bool valid = row_raw < B;
+    const int row = valid ? row_raw : B - 1;
+    const int G = 4 * H;
+
+    for (int m = lane; m < G; m += 64) ds[w][m] = dpre_tsum[(size_t)row * G + m];
+    __syncthreads();
+    // dh0 = dpre_tsum . W_ih(dec layer 0)  (the decoder input is the same h0 at every step, temporal_vae.py:68)
+    for (int k = lane; k < H; k += 64) {
+        float acc = 0.f;
+        for (int m = 0; m < G; ++m) acc = fmaf(ds[w][m], W_ih_dec0[(size_t)m * H + k], acc);
+        const float h0 = hb.h0[(size_t)row * H + k];
+        const float dp = acc * (1.0f - h0 * h0);
+        dl[w][k] = dp;
+        if (valid) { hb.dh0[(size_t)row * H + k] = acc; hb.dpre_l2h[(size_t)row * H + k] = dp; }
+    }
+    __syncthreads();
+    if (lane < Z) {
+        float dz = 0.f;
+        for (int k = 0; k < H; ++k) dz = fmaf(dl[w][k], p.l2h_w[(size_t)k * Z + lane], dz);
+        const size_t i = (size_t)row * Z + lane;
+        const float sd = expf(0.5f * hb.lv[i]);
+        const float dm = dz + d_mu[i];
+        const float dv = dz * eps[i] * 0.5f * sd + d_lv[i];
+        dmz[w][lane] = dm; dmz[w][ZMAX + lane] = dv;
+        if (valid) { hb.dmu[i] = dm; hb.dlv[i] = dv; }
+    }
+    __syncthreads();
+    float dxh[HMAX / 64], xh[HMAX / 64], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < HMAX / 64; ++i) {
+        const int k = lane + 64 * i;
+        dxh[i] = 0.f; xh[i] = 0.f;
+        if (k < H) {
+            float dy = 0.f;
+            for (int z = 0; z < Z; ++z)
+                dy += dmz[w][z] * p.mu_w[(size_t)z * H + k] + dmz[w][ZMAX + z] * p.lv_w[(size_t)z * H + k];
+            if (layer_norm) {
+                xh[i] = hb.xhat[(size_t)row * H + k];
+                dxh[i] = dy * p.ln_w[k];
+                if (valid) { hb.dy[(size_t)row * H + k] = dy; hb.dyx[(size_t)row * H + k] = dy * xh[i]; }
+                s1 += dxh[i]; s2 += dxh[i] * xh[i];
+            } else if (valid) {
+                hb.dh_last[(size_t)row * H + k] = dy;
+            }
+        }
+    }
+    if (layer_norm) {
+        const float m1 = wave_sum(s1) / (float)H, m2 = wave_sum(s2) / (float)H;
+        const float rstd = hb.rstd[row];
+#pragma unroll
+        for (int i = 0; i < HMAX / 64; ++i) {
+            const int k = lane + 64 * i;
+            if (k < H && valid) hb.dh_last[(size_t)row * H + k] = rstd * (dxh[i] - m1 - xh[i] * m2);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ output layer + score
+constexpr int DMAX = 16;
+__global__ void __launch_bounds__(256) out_fwd_kernel(int T, int D, int H, const float* __restrict__ h_seq,
+                                                      const float* __restrict__ Wout, const float* __restrict__ bout,
+                                                      const float* __restrict__ x, float* __restrict__ recon,
+                                                      float* __restrict__ score) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float wreg[DMAX][HMAX / 64];
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d)
+#pragma unroll
+        for (int i = 0; i < HMAX / 64; ++i) {
+            const int k = lane + 64 * i;
+            wreg[d][i] = (d < D && k < H) ? Wout[(size_t)d * H + k] : 0.f;
+        }
+    const float bias = lane < D ? bout[lane] : 0.f;
+    float sq = 0.f;
+    for (int t = w; t < T; t += 4) {
+        const float* h = h_seq + ((size_t)b * T + t) * H;
+        float hv[HMAX / 64];
+#pragma unroll
+        for (int i = 0; i < HMAX / 64; ++i) { const int k = lane + 64 * i; hv[i] = k < H ? h[k] : 0.f; }
+        float mine = 0.f;
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) {
+            if (d < D) {
+                float a = 0.f;
+#pragma unroll
+                for (int i = 0; i < HMAX / 64; ++i) a = fmaf(hv[i], wreg[d][i], a);
+                a = wave_sum(a);
+                if (lane == d) mine = a;
+            }
+        }
+        if (lane < D) {
+            const size_t o = ((size_t)b * T + t) * D + lane;
+            const float r = mine + bias;
+            if (recon) recon[o] = r;
+            const float e = x[o] - r;
+            sq = fmaf(e, e, sq);
+        }
+    }
+    sq = wave_sum(sq);
+    if (lane == 0) red[w] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0 && score) score[b] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)(T * D);
+}
+
+// ------------------------------------------------------------------------------------------------ loss + its gradients
+__global__ void __launch_bounds__(256) vae_loss_kernel(int B, int T, int D, int Z, const float* __restrict__ x,
+                                                       const float* __restrict__ recon, const float* __restrict__ mu,
+                                                       const float* __restrict__ lv, const float* __restrict__ score,
+                                                       float kl_w, float* __restrict__ d_recon, float* __restrict__ d_mu,
+                                                       float* __restrict__ d_lv, float* __restrict__ losses) {
+    const size_t n = (size_t)B * T * D;
+    const float sc = 2.0f / (float)n;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        d_recon[i] = (recon[i] - x[i]) * sc;
+    if (blockIdx.x == 0) {
+        __shared__ float red[2][4];
+        const int nz = B * Z;
+        const float kz = kl_w / (float)nz;
+        float ks = 0.f, rs = 0.f;
+        for (int i = threadIdx.x; i < nz; i += 256) {
+            const float m = mu[i], l = lv[i], e = expf(l);
+            ks += 1.0f + l - m * m - e;
+            d_mu[i] = kz * m;
+            d_lv[i] = -0.5f * kz * (1.0f - e);
+        }
+        for (int i = threadIdx.x; i < B; i += 256) rs += score[i];
+        ks = wave_sum(ks); rs = wave_sum(rs);
+        if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ks; red[1][threadIdx.x >> 6] = rs; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float kl = -0.5f * ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (float)nz;
+            const float rc = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)B;
+            losses[0] = rc + kl_w * kl; losses[1] = rc; losses[2] = kl;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ column sums
+constexpr int CS_ROWS = 2048;    // rows per block (grid.y chunks), fixed summation order
+__global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ A, int lda, int R, int N,
+                                                     float* __restrict__ out) {
+    // block: 64 columns x 4 row-groups over one chunk of CS_ROWS rows; writes out[chunk*N + c]
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * CS_ROWS, r1 = min(R, r0 + CS_ROWS);
+    float s = 0.f;
+    if (c < N)
+        for (int r = r0 + g; r < r1; r += 4) s += A[(size_t)r * lda + c];
+    red[g][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (g == 0 && c < N)
+        out[(size_t)blockIdx.y * N + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __restrict__ partial, int nparts, size_t n,
+                                                              float* __restrict__ out0, float* __restrict__ out1) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * n + i];
+    out0[i] = s;
+    if (out1) out1[i] = s;
+}
+
+// ------------------------------------------------------------------------------------------------ weight packing
+__global__ void __launch_bounds__(256) pack_fwd_f32_kernel(const float* __restrict__ W, int H, int K, float* __restrict__ dst) {
+    const int Kp = (K + 15) & ~15, KQ = Kp >> 2, S4 = KQ >> 2;
+    const size_t n = (size_t)4 * H * Kp;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int e = i & 3, lane = (i >> 2) & 63;
+        size_t r = i >> 8;
+        const int g = r & 3; r >>= 2;
+        const int s4 = r % S4, ht = r / S4;
+        const int row = g * H + ht * 16 + (lane & 15), k = (lane >> 4) * KQ + 4 * s4 + e;
+        dst[i] = k < K ? W[(size_t)row * K + k] : 0.f;
+    }
+}
+__global__ void __launch_bounds__(256) pack_bwd_f32_kernel(const float* __restrict__ W, int H, int M, float* __restrict__ dst) {
+    const int S4 = H >> 2, Mp = (M + 15) & ~15;
+    const size_t n = (size_t)Mp * 4 * H;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int e = i & 3, lane = (i >> 2) & 63;
+        const size_t r = i >> 8;
+        const int s4 = r % S4, mt = r / S4;
+        const int k = (lane >> 4) * H + 4 * s4 + e, m = mt * 16 + (lane & 15);
+        dst[i] = m < M ? W[(size_t)k * M + m] : 0.f;
+    }
+}
+__global__ void __launch_bounds__(256) bias_sum_kernel(const float* __restrict__ a, const float* __restrict__ b, int n, float* __restrict__ dst) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = a[i] + b[i];
+}
+
+}  // namespace
+
+int launch_head_fwd(int B, int H, int Z, int layer_norm, const float* h_last, const float* eps, const HeadParams& p,
+                    const HeadBufs& hb, float* mu_out, float* lv_out, hipStream_t s) {
+    SHM_REQUIRE(H <= HMAX && Z <= ZMAX, SHM_EINVAL, "head: H=%d (<=%d) Z=%d (<=%d) unsupported", H, HMAX, Z, ZMAX);
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, s, B, H, Z, layer_norm, h_last, eps, p, hb, mu_out, lv_out);
+    SHM_LAUNCH_CHECK();
+    return SHM_OK;
+}
+int launch_head_bwd(int B, int H, int Z, int layer_norm, const float* dpre_tsum, const float* W_ih_dec0, const float* eps,
+                    const float* d_mu, const float* d_lv, const HeadParams& p, const HeadBufs& hb, hipStream_t s) {
+    SHM_REQUIRE(H <= HMAX && Z <= ZMAX, SHM_EINVAL, "head: H=%d Z=%d unsupported", H, Z);
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, s, B, H, Z, layer_norm, dpre_tsum, W_ih_dec0, eps, d_mu, d_lv, p, hb);
+    SHM_LAUNCH_CHECK();
+    return SHM_OK;
+}
+int launch_out_fwd(int B, int T, int D, int H, const float* h_seq, const float* Wout, const float* bout, const float* x,
+                   float* recon, float* score, hipStream_t s) {
+    SHM_REQUIRE(D <= DMAX && H <= HMAX, SHM_EINVAL, "out: D=%d (<=%d) H=%d unsupported", D, DMAX, H);
+    hipLaunchKernelGGL(out_fwd_kernel, dim3(B), dim3(256), 0, s, T, D, H, h_seq, Wout, bout, x, recon, score);
+    SHM_LAUNCH_CHECK();
+    return SHM_OK;
+}
+int launch_vae_loss(int B, int T, int D, int Z, const float* x, const float* recon, const float* mu, const float* lv,
+                    float kl_w, float* d_recon, float* d_mu, float* d_lv, float* score, float* losses, hipStream_t s) {
+    const size_t n = (size_t)B * T * D;
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(vae_loss_kernel, dim3(blocks), dim3(256), 0, s, B, T, D, Z, x, recon, mu, lv, score, kl_w, d_recon, d_mu, d_lv, losses);
+    SHM_LAUNCH_CHECK();
+    return SHM_OK;
+}
+size_t colsum_scratch_elems(int R, int N) { return (size_t)ceil_div(R, CS_ROWS) * N; }
+int launch_reduce_partials(const float* partial, int nparts, size_t n, float* out0, float* out1, hipStream_t s) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, partial, nparts, n, out0, out1);
+    SHM_LAUNCH_CHECK();
+    return SHM_OK;
+}
+int launch_colsum(const float* A, int lda, int R, int N, float* out0, float* out1, float* scratch, hipStream_t s) {
+    const int chunks = ceil_div(R, CS_ROWS);
+    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 64), chunks), dim3(256), 0, s, A, lda, R, N, scratch);
+    SHM_LAUNCH_CHECK();
+    return launch_reduce_partials(scratch, chunks, (size_t)N, out0, out1, s);
+}
+int launch_pack_fwd_f32(const float* W, int H, int K, float* dst, hipStream_t s) {
+    const size_t n = fwd_pack_elems(H, K);
+    hipLaunchKernelGGL(pack_fwd_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, H, K, dst);
+    SHM_LAUNCH_CHECK();
+    return SHM_OK;
+}
+int launch_pack_bwd_f32(const float* W, int H, int M, float* dst, hipStream_t s) {
+    const size_t n = bwd_pack_elems(H, M);
+    hipLaunchKernelGGL(pack_bwd_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, H, M, dst);
+    SHM_LAUNCH_CHECK();
+    return SHM_OK;
+}
+int launch_bias_sum(const float* b_ih, const float* b_hh, int n, float* dst, hipStream_t s) {
+    hipLaunchKernelGGL(bias_sum_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, b_ih, b_hh, n, dst);
+    SHM_LAUNCH_CHECK();
+    return SHM_OK;
+}
+
+}  // namespace shm

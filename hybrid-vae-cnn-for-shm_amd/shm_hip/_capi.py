@@ -1,0 +1,80 @@
+"""ctypes binding of include/shm_hip.h (libshm_hip.so, built in-tree by csrc/Makefile).
+
+There is no CPU fallback: importing this module without the built library raises ImportError, and every
+entry point raises RuntimeError with shm_last_error() on a non-zero status.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+_LIB_PATH = Path(__file__).resolve().parent.parent / "csrc" / "libshm_hip.so"
+
+SHM_PREC_F32, SHM_PREC_BF16 = 0, 1
+
+
+class VaeConfig(C.Structure):
+    _fields_ = [("input_dim", C.c_int32), ("latent_dim", C.c_int32), ("hidden_dim", C.c_int32),
+                ("num_layers", C.c_int32), ("layer_norm", C.c_int32), ("precision", C.c_int32),
+                ("dropout", C.c_float)]
+
+
+class TensorDesc(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("offset", C.c_int64), ("ndim", C.c_int32), ("shape", C.c_int32 * 4)]
+
+
+def _load():
+    if not _LIB_PATH.exists():
+        raise ImportError(
+            f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"(or `make -C {_LIB_PATH.parent}`); this package has no CPU fallback")
+    lib = C.CDLL(str(_LIB_PATH))
+    vp, f32p = C.c_void_p, C.c_void_p
+    cfgp = C.POINTER(VaeConfig)
+    sig = {
+        "shm_last_error": (C.c_char_p, []),
+        "shm_version": (C.c_int, []),
+        "shm_vae_param_count": (C.c_int64, [cfgp]),
+        "shm_vae_param_layout": (C.c_int, [cfgp, C.POINTER(TensorDesc), C.c_int]),
+        "shm_vae_plan_create": (C.c_int, [cfgp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]),
+        "shm_vae_plan_destroy": (None, [vp]),
+        "shm_vae_plan_workspace_bytes": (C.c_size_t, [vp]),
+        "shm_vae_pack_weights": (C.c_int, [vp, f32p, vp, vp]),
+        "shm_vae_forward": (C.c_int, [vp, f32p, f32p, f32p, f32p, f32p, f32p, C.c_int32, C.c_uint64, vp, vp]),
+        "shm_vae_loss": (C.c_int, [vp, f32p, C.c_float, f32p, vp, vp]),
+        "shm_vae_backward": (C.c_int, [vp, f32p, f32p, f32p, f32p, f32p, vp, vp]),
+        "shm_adam_scratch_bytes": (C.c_size_t, [C.c_int64]),
+        "shm_adam_step": (C.c_int, [C.c_int64, f32p, f32p, f32p, f32p, C.c_int32, C.c_float, C.c_float, C.c_float,
+                                    C.c_float, C.c_float, C.c_float, C.c_float, vp, f32p, vp]),
+        "shm_dropout_keep_mask": (None, [C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype, fn.argtypes = res, args
+    return lib, tuple(sig)
+
+
+lib, EXPORTS = _load()
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = lib.shm_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (status {status}): {msg}")
+
+
+def make_config(input_dim, latent_dim, hidden_dim, num_layers, layer_norm, dropout, precision=SHM_PREC_F32) -> VaeConfig:
+    return VaeConfig(int(input_dim), int(latent_dim), int(hidden_dim), int(num_layers), int(bool(layer_norm)),
+                     int(precision), float(dropout))
+
+
+def param_layout(cfg: VaeConfig):
+    """[(name, offset, shape)] in state_dict order, and the flat buffer length."""
+    n = lib.shm_vae_param_layout(C.byref(cfg), None, 0)
+    if n < 0:
+        check(n, "shm_vae_param_layout")
+    arr = (TensorDesc * n)()
+    lib.shm_vae_param_layout(C.byref(cfg), arr, n)
+    total = lib.shm_vae_param_count(C.byref(cfg))
+    out = [(d.name.decode(), int(d.offset), tuple(int(d.shape[i]) for i in range(d.ndim))) for d in arr]
+    return out, int(total)

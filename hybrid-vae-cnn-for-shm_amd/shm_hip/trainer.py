@@ -1,0 +1,113 @@
+"""Fused LSTM-VAE train step (reference 4DOF/Scripts/03_train_vae.py:260-271) and its data-parallel form.
+
+One step = forward -> loss -> backward -> [all-reduce of ONE flat gradient bucket] -> clip_grad_norm_ -> Adam,
+all through the C ABI on the current HIP stream; no host synchronisation inside a step (the reference's three
+.item() calls per step, 03_train_vae.py:275-277, become one read of a 4-float device buffer when the caller asks).
+
+Data parallelism: one process per GPU, every rank holds the full 1.9 MB model, windows are
+sharded by rank, gradients are summed with a single torch.distributed all-reduce (backend "nccl" = RCCL over xGMI)
+and scaled by 1/world inside the Adam kernel; every rank then applies the bit-identical update, so parameters
+never need re-broadcasting after step 0.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from ._capi import lib, check
+from .vae import _ptr, _stream
+
+
+def shard_indices(n_items: int, rank: int, world: int):
+    """Indices of the items rank `rank` owns: r, r+world, r+2*world, ... (SURVEY.md §8e partitioning)."""
+    return range(rank, n_items, world)
+
+
+class FlatAllReduce:
+    """Sum-all-reduce of one flat bucket; group=None and world 1 is a no-op.  Kept separate so the CPU tests can
+    drive the same exchange logic over gloo."""
+
+    def __init__(self, group=None):
+        self.dist = None
+        self.world = 1
+        self.group = group
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            self.dist = dist
+            self.world = dist.get_world_size(group)
+
+    def __call__(self, bucket: torch.Tensor) -> float:
+        """Reduces in place; returns the scale (1/world) the optimiser must apply to turn the sum into a mean."""
+        if self.world > 1:
+            self.dist.all_reduce(bucket, op=self.dist.ReduceOp.SUM, group=self.group)
+        return 1.0 / self.world
+
+    def broadcast(self, t: torch.Tensor, src: int = 0):
+        if self.world > 1:
+            self.dist.broadcast(t, src=src, group=self.group)
+
+
+class VAETrainer:
+    """Fused train step for a Scripts.Models.temporal_vae.TemporalVAE living on a CUDA (ROCm) device."""
+
+    def __init__(self, model, lr=1e-3, weight_decay=1e-5, betas=(0.9, 0.999), eps=1e-8, max_norm=2.0,
+                 seed=42, group=None, sync_params=True):
+        self.model = model
+        self.engine = model._engine
+        self.flat = self.engine.bind_parameters(dict(model.named_parameters()))
+        dev = self.flat.device
+        n = self.engine.n_flat
+        self.grads = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.scratch = torch.zeros(int(lib.shm_adam_scratch_bytes(n)), dtype=torch.uint8, device=dev)
+        self.stats = torch.zeros(4, dtype=torch.float32, device=dev)      # loss, recon, kl, grad_norm
+        self.lr, self.wd, self.betas, self.eps, self.max_norm = lr, weight_decay, betas, eps, max_norm
+        self.step_count = 0
+        self.comm = FlatAllReduce(group)
+        self.gen = torch.Generator(device=dev)
+        rank = self.comm.dist.get_rank(group) if self.comm.world > 1 else 0
+        self.gen.manual_seed(seed + 7919 * rank)        # eps / dropout streams differ per rank (different windows)
+        self.seed = seed + 7919 * rank
+        if sync_params:
+            self.comm.broadcast(self.flat, 0)
+            self.engine.mark_dirty()
+
+    def step(self, x: torch.Tensor, kl_w: float, eps: torch.Tensor | None = None, drop_seed: int | None = None):
+        """One optimiser step on the local shard x [B,T,D]; returns the device tensor [loss, recon, kl, grad_norm]."""
+        eng = self.engine
+        if self.flat.data_ptr() != eng.flat.data_ptr():
+            raise RuntimeError("model parameters were re-allocated (e.g. .to()) after the trainer was built")
+        B = x.size(0)
+        if eps is None:
+            eps = torch.randn(B, eng.cfg.latent_dim, dtype=torch.float32, device=x.device, generator=self.gen)
+        self.step_count += 1
+        if drop_seed is None:
+            drop_seed = (self.seed << 20) + self.step_count
+        train_mode = self.model.training and self.model.dropout > 0.0
+        _, _, _, _, pl, xc = eng.forward(x, eps, training_plan=True, train_mode=train_mode, drop_seed=drop_seed,
+                                         want_recon=False)
+        eng.loss(pl, xc, float(kl_w), self.stats)
+        eng.backward(pl, xc, self.grads)
+        scale = self.comm(self.grads)
+        b1, b2 = self.betas
+        check(lib.shm_adam_step(C.c_int64(eng.n_flat), _ptr(self.flat), _ptr(self.grads), _ptr(self.exp_avg),
+                                _ptr(self.exp_avg_sq), self.step_count, C.c_float(self.lr), C.c_float(b1), C.c_float(b2),
+                                C.c_float(self.eps), C.c_float(self.wd),
+                                C.c_float(self.max_norm if self.max_norm is not None else 0.0), C.c_float(scale),
+                                _ptr(self.scratch), C.c_void_p(self.stats.data_ptr() + 12), _stream()), "shm_adam_step")
+        eng.mark_dirty()
+        return self.stats
+
+    @torch.no_grad()
+    def evaluate(self, x: torch.Tensor, kl_w: float, eps: torch.Tensor | None = None):
+        """Validation pass of 03_train_vae.py:284-299: same loss, no state saved, no update. Returns [loss, recon, kl]."""
+        eng = self.engine
+        B = x.size(0)
+        if eps is None:
+            eps = torch.randn(B, eng.cfg.latent_dim, dtype=torch.float32, device=x.device, generator=self.gen)
+        _, mu, lv, score, _, _ = eng.forward(x, eps, training_plan=False, train_mode=False, want_score=True, want_recon=False)
+        recon = score.mean()
+        kl = -0.5 * torch.mean(1.0 + lv - mu.pow(2) - lv.exp())
+        return torch.stack([recon + kl_w * kl, recon, kl])

@@ -1,0 +1,112 @@
+/*
+ * shm_hip.h — C ABI of the MI355X (gfx950) LSTM-VAE / CNN hot path.
+ *
+ * The reference (Ogunleyemma1/Hybrid-VAE-CNN-for-SHM) has no FFI layer: its boundary for this path is
+ * the Python module API of Scripts/Models.  Each entry point below replaces the PyTorch
+ * arithmetic behind one of those reference call sites; the Python mirror in
+ * hybrid-vae-cnn-for-shm_amd/Scripts/Models binds them through ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - plain C types only: device pointers, sizes, a hipStream_t passed as void*;
+ *   - every buffer is owned by the caller (torch tensors in the Python mirror); the library allocates
+ *     no device memory — a plan is a host-side description of offsets into a caller-supplied workspace;
+ *   - calls are asynchronous on the given stream; one host thread per plan;
+ *   - return value 0 = ok, otherwise a negative SHM_E* code or a positive hipError_t;
+ *     shm_last_error() gives the text for the calling thread.  No C++ exception crosses the ABI.
+ *   - parameters travel as ONE flat fp32 buffer in the reference's state_dict order
+ *     (4DOF/Scripts/Models/temporal_vae.py:28-49; shm_vae_param_layout() enumerates it), gradients
+ *     and Adam moments as flat buffers of the same layout.
+ */
+#ifndef SHM_HIP_H
+#define SHM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SHM_OK            0
+#define SHM_EINVAL       -1   /* bad argument / unsupported shape */
+#define SHM_EWORKSPACE   -2   /* workspace too small */
+#define SHM_ESTATE       -3   /* call order violated (e.g. backward without a training forward) */
+
+enum { SHM_PREC_F32 = 0, SHM_PREC_BF16 = 1 };
+
+/* Constructor arguments of TemporalVAE (4DOF/Scripts/Models/temporal_vae.py:14-21; the 1_DOF variant
+ * 1_DOF/Scripts/Models/temporal_vae.py:11 has no LayerNorm -> layer_norm = 0). */
+typedef struct shm_vae_config {
+    int32_t input_dim;     /* D */
+    int32_t latent_dim;    /* Z  (<= 64) */
+    int32_t hidden_dim;    /* H  in {32, 64, 128} */
+    int32_t num_layers;    /* L  in {1, 2} */
+    int32_t layer_norm;    /* 1 = nn.LayerNorm on h_n[-1] (eps 1e-5, biased variance) */
+    int32_t precision;     /* SHM_PREC_F32: fp32 MFMA parity path; SHM_PREC_BF16: bf16 MFMA, fp32 accumulate/state */
+    float   dropout;       /* nn.LSTM inter-layer dropout p (train mode, L > 1 only) */
+} shm_vae_config;
+
+typedef struct shm_tensor_desc {
+    char    name[48];      /* state_dict key, e.g. "encoder_lstm.weight_ih_l0" */
+    int64_t offset;        /* element offset into the flat fp32 buffer */
+    int32_t ndim;
+    int32_t shape[4];
+} shm_tensor_desc;
+
+typedef struct shm_vae_plan shm_vae_plan;   /* opaque, host memory only */
+
+const char* shm_last_error(void);
+int  shm_version(void);
+
+/* ---- parameter layout (replaces nn.Module.state_dict() ordering, temporal_vae.py:28-49) ---- */
+int64_t shm_vae_param_count(const shm_vae_config* cfg);
+/* writes up to max descriptors, returns the number of parameter tensors (26 for L=2 with LayerNorm) */
+int  shm_vae_param_layout(const shm_vae_config* cfg, shm_tensor_desc* out, int max);
+
+/* ---- plan: fixes (config, batch B, window length T) and lays out the workspace ---- */
+int  shm_vae_plan_create(const shm_vae_config* cfg, int32_t B, int32_t T, int32_t training, shm_vae_plan** out);
+void shm_vae_plan_destroy(shm_vae_plan* plan);
+size_t shm_vae_plan_workspace_bytes(const shm_vae_plan* plan);
+
+/* Re-pack the flat fp32 parameters into MFMA fragment order inside the workspace.  Must run after every
+ * parameter change and before forward; it also keeps a flat copy for the head / output layer, so forward and
+ * backward read parameters only from the workspace. */
+int  shm_vae_pack_weights(shm_vae_plan* plan, const float* params, void* workspace, void* stream);
+
+/* TemporalVAE.forward (temporal_vae.py:72-77) + per-window score ((x-recon)^2).mean(dim=(1,2)),
+ * 04_vae_thresholding.py:122.  eps[B,Z] is the reparameterisation noise (temporal_vae.py:62) supplied by
+ * the caller.  recon/mu/logvar/score may each be NULL.  train_mode != 0 applies inter-layer dropout with
+ * the counter RNG keyed by drop_seed and, if the plan is a training plan, saves the state backward needs. */
+int  shm_vae_forward(shm_vae_plan* plan, const float* x, const float* eps,
+                     float* recon, float* mu, float* logvar, float* score,
+                     int32_t train_mode, uint64_t drop_seed, void* workspace, void* stream);
+
+/* Loss of 03_train_vae.py:264-266: recon = mean((recon-x)^2), kl = -0.5*mean(1+lv-mu^2-exp(lv)),
+ * loss = recon + kl_w*kl.  Writes losses[0..2] = {loss, recon, kl} (device, fp32) and leaves
+ * dLoss/d(recon,mu,logvar) in the workspace for shm_vae_backward(..., NULL, NULL, NULL, ...). */
+int  shm_vae_loss(shm_vae_plan* plan, const float* x, float kl_w, float* losses, void* workspace, void* stream);
+
+/* loss.backward() (03_train_vae.py:269): BPTT through decoder, head and encoder.  d_recon[B,T,D],
+ * d_mu[B,Z], d_logvar[B,Z] are the upstream gradients (all NULL: use those left by shm_vae_loss).
+ * grads: flat fp32 buffer, overwritten (zero_grad(set_to_none=True) semantics). */
+int  shm_vae_backward(shm_vae_plan* plan, const float* x,
+                      const float* d_recon, const float* d_mu, const float* d_logvar,
+                      float* grads, void* workspace, void* stream);
+
+/* clip_grad_norm_(max_norm) + torch.optim.Adam step (03_train_vae.py:222,270-271) over flat buffers.
+ * grad_scale multiplies the gradients first (1/world_size after a sum all-reduce).  max_norm <= 0: no clipping.
+ * weight decay is L2-coupled (g += wd*p).  step is 1-based.  scratch: >= shm_adam_scratch_bytes(n) device bytes.
+ * out_norm (device, 1 float, may be NULL) receives the pre-clip total norm. */
+size_t shm_adam_scratch_bytes(int64_t n);
+int  shm_adam_step(int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                   int32_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                   float max_norm, float grad_scale, void* scratch, float* out_norm, void* stream);
+
+/* Host-side replica of the dropout counter RNG (so tests can rebuild the masks the kernels used).
+ * keep[i] = 1 if element (b,t,k) of the layer-0 output of stack `stack` (0 = encoder, 1 = decoder) is kept. */
+void shm_dropout_keep_mask(uint64_t drop_seed, int32_t stack, int32_t B, int32_t T, int32_t H, float p, uint8_t* keep);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHM_HIP_H */

@@ -1,0 +1,66 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/shm_hip.h declares, and its
+parameter layout is the reference's state_dict layout (no GPU compute calls here)."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden, split_prefix
+
+
+def _declared_symbols():
+    text = (ROOT / "include" / "shm_hip.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(shm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from shm_hip import _capi
+    declared = _declared_symbols()
+    assert len(declared) >= 12
+    for name in declared:
+        assert hasattr(_capi.lib, name), f"{name} declared in include/shm_hip.h but not exported"
+    assert set(_capi.EXPORTS) == set(declared), set(_capi.EXPORTS) ^ set(declared)
+    assert _capi.lib.shm_version() >= 1
+
+
+@pytest.mark.parametrize("name", ["vae_fwd_ns_h128", "vae_fwd_ref_h128", "vae_fwd_1dof", "vae_fwd_openlab"])
+def test_param_layout_is_the_reference_state_dict(name):
+    from shm_hip import _capi
+    g = load_golden(name)
+    cfg = g["cfg"]
+    c = _capi.make_config(cfg["input_dim"], cfg["latent_dim"], cfg["hidden_dim"], cfg["num_layers"], cfg["layer_norm"], cfg["dropout"])
+    layout, total = _capi.param_layout(c)
+    ref = split_prefix(g, "p.")
+    assert [n for n, _, _ in layout] == list(ref.keys())          # same keys, same order
+    for n, off, shape in layout:
+        assert tuple(ref[n].shape) == shape, n
+        assert off % 4 == 0
+    n_true = sum(v.size for v in ref.values())
+    assert n_true <= total < n_true + 4 * len(layout)
+
+
+def test_invalid_configs_are_rejected_with_a_message():
+    from shm_hip import _capi
+    bad = _capi.make_config(4, 16, 100, 2, True, 0.3)             # hidden_dim 100 unsupported
+    assert _capi.lib.shm_vae_param_count(C.byref(bad)) < 0
+    assert b"hidden_dim" in _capi.lib.shm_last_error()
+    handle = C.c_void_p(0)
+    ok = _capi.make_config(4, 16, 128, 2, True, 0.3)
+    assert _capi.lib.shm_vae_plan_create(C.byref(ok), 0, 256, 1, C.byref(handle)) != 0     # empty batch
+    assert _capi.lib.shm_vae_plan_create(C.byref(ok), 512, 256, 1, C.byref(handle)) == 0
+    nbytes = _capi.lib.shm_vae_plan_workspace_bytes(handle)
+    assert 1 << 30 < nbytes < 8 << 30                              # ~2 GB of saved state at the north-star shape
+    _capi.lib.shm_vae_plan_destroy(handle)
+
+
+def test_dropout_mask_replica_statistics():
+    from shm_hip import _capi
+    buf = np.zeros(64 * 50 * 32, dtype=np.uint8)
+    _capi.lib.shm_dropout_keep_mask(C.c_uint64(77), 0, 64, 50, 32, C.c_float(0.3), buf.ctypes.data_as(C.c_void_p))
+    assert abs(buf.mean() - 0.7) < 0.01
+    buf2 = np.zeros_like(buf)
+    _capi.lib.shm_dropout_keep_mask(C.c_uint64(77), 1, 64, 50, 32, C.c_float(0.3), buf2.ctypes.data_as(C.c_void_p))
+    assert 0.3 < (buf != buf2).mean() < 0.5                       # independent streams per stack
