@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py — LSTM-VAE training throughput (windows/s) on MI355X, BASELINE.json's metric.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]            (N=1 default)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (driver, N>1)
+
+Workload (BASELINE.json configs[1]): TemporalVAE(input_dim=4, latent_dim=16, hidden_dim=128,
+num_layers=2, dropout=0.3), seed-42 init, per-GPU batch 512 windows of T=256 x 4 channels, synthetic N(0,1)
+windows resident in HBM before the timed region.  A step = forward + MSE/KL loss + backward + gradient all-reduce
+(N>1) + clip_grad_norm_(2.0) + Adam(lr 1e-3, wd 1e-5), kl_w = 0.5 — 4DOF/Scripts/03_train_vae.py:260-271.
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+for p in (str(ROOT), str(ROOT / "hybrid-vae-cnn-for-shm_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+B_PER_GPU, T, D, H, Z, L = 512, 256, 4, 128, 16, 2
+KL_W = 0.5
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}       # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def alg_flops_forward_per_window():
+    """F_alg = T[2G(D+H) + (L-1)4GH + L*4GH + 2HD] + 6HZ - 2GH(T-1), G = 4H (decoder-L0 projection hoisted)."""
+    G = 4 * H
+    F = T * (2 * G * (D + H) + (L - 1) * 2 * G * 2 * H + L * 2 * G * 2 * H + 2 * H * D) + 6 * H * Z
+    return F - 2 * G * H * (T - 1)
+
+
+def kernel_alg_flops(name, B):
+    """Algorithmic FLOPs of ONE launch of a profiled kernel (MFMA contractions only; pointwise excluded)."""
+    G = 4 * H
+    kind, _, inst = name.partition(".")
+    if kind == "lstm_fwd":
+        k_in = {"enc0": D, "enc1": H, "dec0": 0, "dec1": H}[inst]          # dec0: constant input, projected once
+        return B * T * 2 * G * (k_in + H) + (B * 2 * G * H if inst == "dec0" else 0)
+    if kind == "lstm_bwd":
+        k_dx = {"enc0": 0, "enc1": H, "dec0": 0, "dec1": H}[inst]          # dx only for layers with a layer below
+        return B * T * 2 * G * (H + k_dx)
+    if kind == "dw_gemm":
+        k_in = {"enc0": D, "enc1": H, "dec0": 0, "dec1": H, "out": 0}[inst]
+        if inst == "out":
+            return B * T * 2 * H * D
+        return B * T * 2 * G * (H + k_in) + (B * 2 * G * H if inst == "dec0" else 0)
+    return 0
+
+
+def cpu_baseline(sample_windows=128, steps=3):
+    """The reference CPU path (oracle/torch_cpu.py: ATen LSTM etc.) timed on this box's host cores, bounded sample."""
+    import torch
+    from oracle.torch_cpu import TorchCpuVAE
+    from Scripts.Models.temporal_vae import TemporalVAE
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(42)
+    ref = TemporalVAE(D, Z, H, L, 0.3)
+    m = TorchCpuVAE({k: v.detach() for k, v in ref.state_dict().items()}, L, True, dropout=0.3)
+    opt = m.make_optimizer(1e-3, 1e-5)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(sample_windows, T, D, generator=g)
+    eps = torch.randn(sample_windows, Z, generator=g)
+    m.train_step(opt, x, eps, KL_W)                       # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m.train_step(opt, x, eps, KL_W)
+    dt = time.perf_counter() - t0
+    return {"value": round(sample_windows * steps / dt, 2), "unit": "windows/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} train steps of {sample_windows} windows (T={T}, D={D}) after 1 warm-up, torch {torch.__version__} CPU fp32, "
+                      f"{cores} threads; same step semantics as the GPU leg"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=2)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from Scripts.Models.temporal_vae import TemporalVAE
+    from shm_hip._capi import lib, check
+    from shm_hip.trainer import VAETrainer
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 through torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    torch.manual_seed(42)
+    model = TemporalVAE(D, Z, H, L, 0.3).to(dev).train()
+    trainer = VAETrainer(model, lr=1e-3, weight_decay=1e-5, max_norm=2.0, seed=42)
+
+    # S1 synthetic windows, resident on the device: no H2D inside the timed region
+    n_resident = 16 * B_PER_GPU
+    gen = torch.Generator().manual_seed(42 + rank)
+    data = torch.randn(n_resident, T, D, generator=gen).to(dev)
+    n_batches = n_resident // B_PER_GPU
+
+    def run(k0, k):
+        for i in range(k0, k0 + k):
+            b = i % n_batches
+            trainer.step(data[b * B_PER_GPU:(b + 1) * B_PER_GPU], KL_W)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    run(0, args.warmup)
+    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.warmup, args.steps)
+    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    stats = trainer.stats.cpu().tolist()
+
+    # per-kernel durations with HIP events on the launch stream (outside the timed region)
+    roof = None
+    if rank == 0 and args.profile_steps > 0:
+        check(lib.shm_profile_begin(), "shm_profile_begin")
+        run(args.warmup + args.steps, args.profile_steps)
+        buf = C.create_string_buffer(1 << 16)
+        check(lib.shm_profile_end(buf, len(buf)), "shm_profile_end")
+        prof = json.loads(buf.value.decode())
+        per = {k: v["ms"] / v["calls"] for k, v in prof.items()}
+        dom = max((k for k in per if kernel_alg_flops(k, B_PER_GPU) > 0), key=lambda k: per[k])
+        fl = kernel_alg_flops(dom, B_PER_GPU)
+        achieved = fl / (per[dom] * 1e-3) / 1e12
+        peak = PEAK_TFLOPS["f32"]
+        roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 5), "traffic": None, "avg_launch_ms": round(per[dom], 4),
+                "alg_flops_per_launch": fl, "kernels_ms": {k: round(v, 4) for k, v in sorted(per.items())}}
+    barrier()
+
+    if rank == 0:
+        total_windows = world * B_PER_GPU * args.steps
+        value = total_windows / dt
+        step_flops = 3 * alg_flops_forward_per_window()
+        out = {
+            "metric": "windows/sec LSTM-VAE train (4DOF, seq256x4ch, bs512) at 1/2/4/8 GPU",
+            "value": round(value, 2), "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "4DOF LSTM-VAE train step: TemporalVAE(D=4,Z=16,H=128,L=2,dropout=0.3), T=256, "
+                                   "batch 512 windows/GPU, fwd+loss+BPTT+clip(2.0)+Adam(1e-3,wd 1e-5), kl_w=0.5",
+                       "global_batch": world * B_PER_GPU, "seq_len": T, "parallelism": f"dp{world}"},
+            "alg_flops_per_window_step": step_flops,
+            "whole_step_mfma_frac": round(value * step_flops / (world * PEAK_TFLOPS["f32"] * 1e12), 5),
+            "final_stats": {"loss": stats[0], "recon": stats[1], "kl": stats[2], "grad_norm": stats[3]},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

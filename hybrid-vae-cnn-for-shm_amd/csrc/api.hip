@@ -5,7 +5,9 @@
 #include <math.h>
 #include <string.h>
 
+#include <map>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "kernels.hpp"
@@ -19,6 +21,24 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+// ---- optional per-kernel timing with HIP events on the launch stream (bench.py's roofline line) -------------
+struct ProfEntry { char name[32]; hipEvent_t e0, e1; };
+static thread_local bool g_prof_on = false;
+static thread_local std::vector<ProfEntry>* g_prof = nullptr;
+struct KernelTimer {
+    hipStream_t s; int idx = -1;
+    KernelTimer(const char* name, hipStream_t stream) : s(stream) {
+        if (!g_prof_on || !g_prof) return;
+        ProfEntry e;
+        snprintf(e.name, sizeof(e.name), "%s", name);
+        if (hipEventCreate(&e.e0) != hipSuccess || hipEventCreate(&e.e1) != hipSuccess) return;
+        (void)hipEventRecord(e.e0, s);
+        g_prof->push_back(e);
+        idx = (int)g_prof->size() - 1;
+    }
+    ~KernelTimer() { if (idx >= 0) (void)hipEventRecord((*g_prof)[idx].e1, s); }
+};
 
 struct LayerInst {
     int In = 0;
@@ -276,6 +296,9 @@ extern "C" int shm_vae_forward(shm_vae_plan* p, const float* x, const float* eps
             a.saved = save ? at<float>(ws, st[l].saved) : nullptr;
             a.B = B; a.T = T; a.In = st[l].In; a.in_const = st[l].in_const ? 1 : 0;
             a.drop_p = l > 0 ? drop : 0.f; a.drop_seed = drop_seed; a.drop_stack = stack;
+            char nm[32];
+            snprintf(nm, sizeof(nm), "lstm_fwd.%s%d", stack == 0 ? "enc" : "dec", l);
+            KernelTimer kt(nm, s);
             int r = launch_lstm_fwd_f32(H, a, s);
             if (r) return r;
         }
@@ -283,12 +306,18 @@ extern "C" int shm_vae_forward(shm_vae_plan* p, const float* x, const float* eps
     };
     const float* prm = at<float>(ws, p->params_copy);
     if ((rc = run_stack(p->enc, x, 0, at<float>(ws, p->h_last)))) return rc;
-    if ((rc = launch_head_fwd(B, H, Z, c.layer_norm, at<float>(ws, p->h_last), at<float>(ws, p->eps), head_params(p, prm),
-                              head_bufs(p, ws), mu, logvar, s))) return rc;
+    {
+        KernelTimer kt("head_fwd", s);
+        if ((rc = launch_head_fwd(B, H, Z, c.layer_norm, at<float>(ws, p->h_last), at<float>(ws, p->eps), head_params(p, prm),
+                                  head_bufs(p, ws), mu, logvar, s))) return rc;
+    }
     if ((rc = run_stack(p->dec, at<float>(ws, p->h0), 1, nullptr))) return rc;
     float* rec = recon ? recon : (p->training ? at<float>(ws, p->recon) : nullptr);
-    if ((rc = launch_out_fwd(B, T, D, H, at<float>(ws, p->dec[L - 1].h_seq), prm + p->out_w, prm + p->out_b, x, rec,
-                             at<float>(ws, p->score), s))) return rc;
+    {
+        KernelTimer kt("out_fwd", s);
+        if ((rc = launch_out_fwd(B, T, D, H, at<float>(ws, p->dec[L - 1].h_seq), prm + p->out_w, prm + p->out_b, x, rec,
+                                 at<float>(ws, p->score), s))) return rc;
+    }
     if (score) SHM_HIP_CHECK(hipMemcpyAsync(score, at<float>(ws, p->score), sizeof(float) * B, hipMemcpyDeviceToDevice, s));
     p->recon_ptr = rec;
     p->fwd_saved = save;
@@ -342,8 +371,11 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
 
     // output layer (temporal_vae.py:70): dW_out[d][k] = sum_r d_recon[r][d] h[r][k]
     const float* h_top = at<float>(ws, p->dec[L - 1].h_seq);
-    if ((rc = gemm(h_top, H, H, d_recon, D, D, BT, grads + p->out_w, 0, 1, 0.f, 0))) return rc;
-    if ((rc = launch_colsum(d_recon, D, BT, D, grads + p->out_b, nullptr, cs, s))) return rc;
+    {
+        KernelTimer kt("dw_gemm.out", s);
+        if ((rc = gemm(h_top, H, H, d_recon, D, D, BT, grads + p->out_w, 0, 1, 0.f, 0))) return rc;
+        if ((rc = launch_colsum(d_recon, D, BT, D, grads + p->out_b, nullptr, cs, s))) return rc;
+    }
 
     auto run_stack_bwd = [&](LayerInst* st, uint32_t stack, const float* x0, bool is_dec) -> int {
         for (int l = L - 1; l >= 0; --l) {
@@ -362,8 +394,17 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
             a.dpre_seq = dpre_seq; a.dpre_tsum = dpre_tsum; a.dx_seq = dx_seq;
             a.B = B; a.T = T; a.In = st[l].In;
             a.drop_p = l > 0 ? drop : 0.f; a.drop_seed = p->drop_seed; a.drop_stack = stack;
-            int r = launch_lstm_bwd_f32(H, a, s);
+            int r;
+            {
+                char nm[32];
+                snprintf(nm, sizeof(nm), "lstm_bwd.%s%d", stack == 0 ? "enc" : "dec", l);
+                KernelTimer kt(nm, s);
+                r = launch_lstm_bwd_f32(H, a, s);
+            }
             if (r) return r;
+            char gnm[32];
+            snprintf(gnm, sizeof(gnm), "dw_gemm.%s%d", stack == 0 ? "enc" : "dec", l);
+            KernelTimer kt(gnm, s);
             // deferred weight gradients of this layer
             if ((r = gemm(dpre_seq, G, G, at<float>(ws, st[l].h_seq), H, H, BT, grads + st[l].w_hh, T, 0, 0.f, 0))) return r;
             if (l > 0) {
@@ -381,6 +422,7 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
     if ((rc = run_stack_bwd(p->dec, 1, nullptr, true))) return rc;
 
     // head: dpre_tsum still holds sum_t dpre of decoder layer 0
+    KernelTimer kt_head("head_bwd+grads", s);
     if ((rc = launch_head_bwd(B, H, Z, c.layer_norm, dpre_tsum, prm + p->dec[0].w_ih, at<float>(ws, p->eps), d_mu, d_logvar,
                               head_params(p, prm), hb, s))) return rc;
     if ((rc = gemm(hb.dpre_l2h, H, H, hb.z, Z, Z, B, grads + p->l2h_w, 0, 0, 0.f, 0))) return rc;
@@ -394,7 +436,40 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
         if ((rc = launch_colsum(hb.dy, H, B, H, grads + p->ln_b, nullptr, cs, s))) return rc;
     }
 
+    kt_head.~KernelTimer(); kt_head.idx = -1;
     if ((rc = run_stack_bwd(p->enc, 0, x, false))) return rc;
+    return SHM_OK;
+}
+
+extern "C" int shm_profile_begin(void) {
+    if (!g_prof) g_prof = new std::vector<ProfEntry>();
+    for (auto& e : *g_prof) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); }
+    g_prof->clear();
+    g_prof_on = true;
+    return SHM_OK;
+}
+
+extern "C" int shm_profile_end(char* json, size_t cap) {
+    g_prof_on = false;
+    SHM_REQUIRE(g_prof && json && cap > 2, SHM_EINVAL, "profile_end: no profile or no buffer");
+    SHM_HIP_CHECK(hipDeviceSynchronize());
+    std::map<std::string, std::pair<int, double>> agg;
+    for (auto& e : *g_prof) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e.e0, e.e1) == hipSuccess) { auto& a = agg[e.name]; a.first += 1; a.second += ms; }
+        (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1);
+    }
+    g_prof->clear();
+    std::string out = "{";
+    bool first = true;
+    for (auto& kv : agg) {
+        char buf[160];
+        snprintf(buf, sizeof(buf), "%s\"%s\": {\"calls\": %d, \"ms\": %.6f}", first ? "" : ", ", kv.first.c_str(), kv.second.first, kv.second.second);
+        out += buf; first = false;
+    }
+    out += "}";
+    SHM_REQUIRE(out.size() + 1 <= cap, SHM_EINVAL, "profile_end: buffer too small (%zu needed)", out.size() + 1);
+    memcpy(json, out.c_str(), out.size() + 1);
     return SHM_OK;
 }
 

@@ -46,6 +46,8 @@ def _load():
         "shm_adam_scratch_bytes": (C.c_size_t, [C.c_int64]),
         "shm_adam_step": (C.c_int, [C.c_int64, f32p, f32p, f32p, f32p, C.c_int32, C.c_float, C.c_float, C.c_float,
                                     C.c_float, C.c_float, C.c_float, C.c_float, vp, f32p, vp]),
+        "shm_profile_begin": (C.c_int, []),
+        "shm_profile_end": (C.c_int, [C.c_char_p, C.c_size_t]),
         "shm_dropout_keep_mask": (None, [C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, vp]),
     }
     for name, (res, args) in sig.items():

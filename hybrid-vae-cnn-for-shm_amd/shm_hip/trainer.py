@@ -55,7 +55,8 @@ class VAETrainer:
                  seed=42, group=None, sync_params=True):
         self.model = model
         self.engine = model._engine
-        self.flat = self.engine.bind_parameters(dict(model.named_parameters()))
+        self._named = dict(model.named_parameters())
+        self.flat = self.engine.bind_parameters(self._named)
         dev = self.flat.device
         n = self.engine.n_flat
         self.grads = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -77,7 +78,7 @@ class VAETrainer:
     def step(self, x: torch.Tensor, kl_w: float, eps: torch.Tensor | None = None, drop_seed: int | None = None):
         """One optimiser step on the local shard x [B,T,D]; returns the device tensor [loss, recon, kl, grad_norm]."""
         eng = self.engine
-        if self.flat.data_ptr() != eng.flat.data_ptr():
+        if eng.bind_parameters(self._named) is not self.flat:
             raise RuntimeError("model parameters were re-allocated (e.g. .to()) after the trainer was built")
         B = x.size(0)
         if eps is None:

@@ -49,6 +49,7 @@ class VAEEngine:
         self.layout, self.n_flat = _capi.param_layout(self.cfg)
         self.flat = None            # torch fp32 [n_flat] on the device
         self._manual_version = 0
+        self._param_version = 0
         self._plans = {}
         self.last_plan = None
 
@@ -78,12 +79,15 @@ class VAEEngine:
                 p.data = flat[off:off + n].view(shape)
             self.flat = flat
             self._plans.clear()
+        # p.data = view keeps each Parameter's OWN version counter, so in-place writes (optimizer.step,
+        # load_state_dict) are seen on the parameters, not on the flat buffer
+        self._param_version = sum(params[name]._version for name, _, _ in self.layout)
         return self.flat
 
     @property
     def version(self):
         """Changes whenever a parameter view is written in place (optimizer step, load_state_dict) or mark_dirty() is called."""
-        return (self._manual_version, self.flat._version if self.flat is not None else -1, id(self.flat))
+        return (self._manual_version, self._param_version, self.flat._version if self.flat is not None else -1, id(self.flat))
 
     def mark_dirty(self):
         """For writers that bypass torch's version counter (raw-pointer Adam in the fused trainer, p.data edits)."""

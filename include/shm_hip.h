@@ -102,6 +102,12 @@ int  shm_adam_step(int64_t n, float* params, float* grads, float* exp_avg, float
                    int32_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
                    float max_norm, float grad_scale, void* scratch, float* out_norm, void* stream);
 
+/* Per-kernel timing with HIP events recorded on the launch stream (used by bench.py for the roofline line).
+ * shm_profile_begin() arms it for the calling thread; shm_profile_end() synchronises the device and writes a JSON
+ * object {"lstm_fwd.enc0": {"calls": n, "ms": total}, ...} into json[cap]. */
+int  shm_profile_begin(void);
+int  shm_profile_end(char* json, size_t cap);
+
 /* Host-side replica of the dropout counter RNG (so tests can rebuild the masks the kernels used).
  * keep[i] = 1 if element (b,t,k) of the layer-0 output of stack `stack` (0 = encoder, 1 = decoder) is kept. */
 void shm_dropout_keep_mask(uint64_t drop_seed, int32_t stack, int32_t B, int32_t T, int32_t H, float p, uint8_t* keep);
