@@ -53,12 +53,31 @@ def kernel_alg_flops(name, B):
     return 0
 
 
-def cpu_baseline(sample_windows=128, steps=3):
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """CPU share of this process (cgroup/affinity aware), capped at the 16 cores a one-GPU box grants."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(sample_windows=128, max_steps=3, budget_s=25.0):
     """The reference CPU path (oracle/torch_cpu.py: ATen LSTM etc.) timed on this box's host cores, bounded sample."""
     import torch
     from oracle.torch_cpu import TorchCpuVAE
     from Scripts.Models.temporal_vae import TemporalVAE
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(42)
     ref = TemporalVAE(D, Z, H, L, 0.3)
@@ -67,10 +86,14 @@ def cpu_baseline(sample_windows=128, steps=3):
     g = torch.Generator().manual_seed(7)
     x = torch.randn(sample_windows, T, D, generator=g)
     eps = torch.randn(sample_windows, Z, generator=g)
+    tw = time.perf_counter()
     m.train_step(opt, x, eps, KL_W)                       # warm-up
+    log(f"cpu baseline warm-up step: {time.perf_counter() - tw:.2f}s on {cores} threads")
     t0 = time.perf_counter()
-    for _ in range(steps):
+    steps = 0
+    while steps < max_steps and (steps == 0 or time.perf_counter() - t0 < budget_s):
         m.train_step(opt, x, eps, KL_W)
+        steps += 1
     dt = time.perf_counter() - t0
     return {"value": round(sample_windows * steps / dt, 2), "unit": "windows/s", "cores": cores, "kind": "port",
             "sample": f"{steps} train steps of {sample_windows} windows (T={T}, D={D}) after 1 warm-up, torch {torch.__version__} CPU fp32, "
@@ -122,12 +145,16 @@ def main():
         if world > 1:
             dist.barrier()
 
+    log(f"rank {rank}/{world}: data resident, starting {args.warmup} warm-up steps")
+    tw = time.perf_counter()
     run(0, args.warmup)
     torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+    log(f"warm-up done in {time.perf_counter() - tw:.2f}s; timing {args.steps} steps")
     t0 = time.perf_counter()
     run(args.warmup, args.steps)
     torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    log(f"timed region: {dt:.3f}s for {args.steps} steps")
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -142,6 +169,7 @@ def main():
         buf = C.create_string_buffer(1 << 16)
         check(lib.shm_profile_end(buf, len(buf)), "shm_profile_end")
         prof = json.loads(buf.value.decode())
+        log("kernel profile: " + json.dumps(prof))
         per = {k: v["ms"] / v["calls"] for k, v in prof.items()}
         dom = max((k for k in per if kernel_alg_flops(k, B_PER_GPU) > 0), key=lambda k: per[k])
         fl = kernel_alg_flops(dom, B_PER_GPU)
