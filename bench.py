@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=2)
+    ap.add_argument("--precision", choices=["bf16", "fp32"], default="fp32")
     args = ap.parse_args()
 
     import torch
@@ -127,7 +128,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     torch.manual_seed(42)
-    model = TemporalVAE(D, Z, H, L, 0.3).to(dev).train()
+    model = TemporalVAE(D, Z, H, L, 0.3, precision=args.precision).to(dev).train()
+    dt_key = "bf16" if args.precision == "bf16" else "f32"
     trainer = VAETrainer(model, lr=1e-3, weight_decay=1e-5, max_norm=2.0, seed=42)
 
     # S1 synthetic windows, resident on the device: no H2D inside the timed region
@@ -174,7 +176,7 @@ def main():
         dom = max((k for k in per if kernel_alg_flops(k, B_PER_GPU) > 0), key=lambda k: per[k])
         fl = kernel_alg_flops(dom, B_PER_GPU)
         achieved = fl / (per[dom] * 1e-3) / 1e12
-        peak = PEAK_TFLOPS["f32"]
+        peak = PEAK_TFLOPS[dt_key]
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 5), "traffic": None, "avg_launch_ms": round(per[dom], 4),
                 "alg_flops_per_launch": fl, "kernels_ms": {k: round(v, 4) for k, v in sorted(per.items())}}
@@ -188,12 +190,12 @@ def main():
             "metric": "windows/sec LSTM-VAE train (4DOF, seq256x4ch, bs512) at 1/2/4/8 GPU",
             "value": round(value, 2), "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": dt_key, "data": "synthetic",
             "config": {"workload": "4DOF LSTM-VAE train step: TemporalVAE(D=4,Z=16,H=128,L=2,dropout=0.3), T=256, "
                                    "batch 512 windows/GPU, fwd+loss+BPTT+clip(2.0)+Adam(1e-3,wd 1e-5), kl_w=0.5",
                        "global_batch": world * B_PER_GPU, "seq_len": T, "parallelism": f"dp{world}"},
             "alg_flops_per_window_step": step_flops,
-            "whole_step_mfma_frac": round(value * step_flops / (world * PEAK_TFLOPS["f32"] * 1e12), 5),
+            "whole_step_mfma_frac": round(value * step_flops / (world * PEAK_TFLOPS[dt_key] * 1e12), 5),
             "final_stats": {"loss": stats[0], "recon": stats[1], "kl": stats[2], "grad_norm": stats[3]},
             "roofline": roof,
         }

@@ -17,7 +17,9 @@ class TemporalVAE(nn.Module):
     (temporal_vae.py:14-49): nn.LSTM / nn.LayerNorm / nn.Linear are kept as parameter containers (so the
     default initialisation consumes the torch RNG exactly like the reference and reference checkpoints load
     with strict=True) but are never called — forward() hands the flat parameter buffer to libshm_hip.so.
-    Extra keyword-only arguments: layer_norm (False gives the 1_DOF model, 1_DOF/Scripts/Models/temporal_vae.py:7-64).
+    Extra keyword-only arguments: layer_norm (False gives the 1_DOF model, 1_DOF/Scripts/Models/temporal_vae.py:7-64);
+    precision: "fp32" (exact-f32 MFMA, the 1e-4 parity path) or "bf16" (bf16 MFMA operands, fp32 accumulate / cell
+    state / master weights — the throughput path, tolerances in DESIGN.md §5).
     """
 
     def __init__(
@@ -29,6 +31,7 @@ class TemporalVAE(nn.Module):
         dropout: float = 0.3,
         *,
         layer_norm: bool = True,
+        precision: str = "fp32",
     ) -> None:
         super().__init__()
         self.input_dim = input_dim
@@ -51,7 +54,11 @@ class TemporalVAE(nn.Module):
                                     batch_first=True, dropout=dropout if num_layers > 1 else 0.0)
         self.output_layer = nn.Linear(hidden_dim, input_dim)
 
-        self._engine = VAEEngine(input_dim, latent_dim, hidden_dim, num_layers, layer_norm, self.dropout)
+        if precision not in ("fp32", "bf16"):
+            raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
+        self.precision = precision
+        self._engine = VAEEngine(input_dim, latent_dim, hidden_dim, num_layers, layer_norm, self.dropout,
+                                 precision=1 if precision == "bf16" else 0)
         self._drop_gen_calls = 0
 
     # ------------------------------------------------------------------ reference API

@@ -45,7 +45,7 @@ struct LayerInst {
     bool in_const = false;
     int64_t w_ih = 0, w_hh = 0, b_ih = 0, b_hh = 0;      // element offsets into the flat parameter buffer
     size_t Wx = 0, Wh = 0, bsum = 0, WhT = 0, WxT = 0;   // byte offsets into the workspace (packed operands)
-    size_t h_seq = 0, saved = 0;
+    size_t h_seq = 0, saved = 0, saved_c = 0;            // bf16 path: saved = gates (bf16), saved_c = cell state (fp32)
 };
 
 }  // namespace shm
@@ -76,7 +76,7 @@ static bool config_ok(const shm_vae_config* c) {
     if (c->num_layers < 1 || c->num_layers > 2) { set_error("num_layers %d unsupported (1, 2)", c->num_layers); return false; }
     if (c->latent_dim < 1 || c->latent_dim > 32) { set_error("latent_dim %d unsupported (1..32)", c->latent_dim); return false; }
     if (c->input_dim < 1 || c->input_dim > 16) { set_error("input_dim %d unsupported (1..16)", c->input_dim); return false; }
-    if (c->precision != SHM_PREC_F32) { set_error("precision %d not built in this version (fp32 only)", c->precision); return false; }
+    if (c->precision != SHM_PREC_F32 && c->precision != SHM_PREC_BF16) { set_error("precision %d unknown (0 = fp32, 1 = bf16)", c->precision); return false; }
     if (!(c->dropout >= 0.f && c->dropout < 1.f)) { set_error("dropout %f out of range", c->dropout); return false; }
     return true;
 }
@@ -193,20 +193,34 @@ extern "C" int shm_vae_plan_create(const shm_vae_config* cfg, int32_t B, int32_t
     p->out_w = find("output_layer.weight"); p->out_b = find("output_layer.bias");
 
     size_t off = 0;
-    auto take = [&](size_t elems) { size_t o = off; off += (elems * sizeof(float) + 255) & ~(size_t)255; return o; };
+    auto take_bytes = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    auto take = [&](size_t elems) { return take_bytes(elems * sizeof(float)); };
+    const bool bf = cfg->precision == SHM_PREC_BF16;
     const size_t tiles = (size_t)ceil_div(B, 16);
     const size_t BT = (size_t)B * T;
     for (int l = 0; l < L; ++l) {
         for (int s = 0; s < 2; ++s) {
             LayerInst& li = s == 0 ? p->enc[l] : p->dec[l];
-            li.Wx = take(fwd_pack_elems(H, li.In));
-            li.Wh = take(fwd_pack_elems(H, H));
             li.bsum = take(4 * H);
-            li.h_seq = take(BT * H);
-            if (training) {
-                li.WhT = take(bwd_pack_elems(H, H));
-                if (l > 0) li.WxT = take(bwd_pack_elems(H, li.In));
-                li.saved = take(tiles * T * 5 * 16 * H);
+            if (bf) {
+                li.Wx = take_bytes(2 * fwd_pack_elems_bf16(H, li.In));
+                li.Wh = take_bytes(2 * fwd_pack_elems_bf16(H, H));
+                li.h_seq = take_bytes(2 * BT * H);
+                if (training) {
+                    li.WhT = take_bytes(2 * bwd_pack_elems_bf16(H, H));
+                    if (l > 0) li.WxT = take_bytes(2 * bwd_pack_elems_bf16(H, li.In));
+                    li.saved = take_bytes(2 * tiles * T * 64 * H);      // 4 gates x 16 windows x H units, bf16
+                    li.saved_c = take(tiles * T * 16 * H);              // cell state, fp32
+                }
+            } else {
+                li.Wx = take(fwd_pack_elems(H, li.In));
+                li.Wh = take(fwd_pack_elems(H, H));
+                li.h_seq = take(BT * H);
+                if (training) {
+                    li.WhT = take(bwd_pack_elems(H, H));
+                    if (l > 0) li.WxT = take(bwd_pack_elems(H, li.In));
+                    li.saved = take(tiles * T * 5 * 16 * H);
+                }
             }
         }
     }
@@ -219,10 +233,12 @@ extern "C" int shm_vae_plan_create(const shm_vae_config* cfg, int32_t B, int32_t
         p->dpre_l2h = take((size_t)B * H); p->dmu = take((size_t)B * Z); p->dlv = take((size_t)B * Z);
         p->dyx = take((size_t)B * H); p->dy = take((size_t)B * H); p->dh_last = take((size_t)B * H); p->dh0 = take((size_t)B * H);
         p->recon = take(BT * D); p->d_recon = take(BT * D); p->d_mu = take((size_t)B * Z); p->d_lv = take((size_t)B * Z);
-        p->dpre_seq = take(BT * 4 * H); p->dx_seq = take(BT * H); p->dpre_tsum = take((size_t)B * 4 * H);
+        p->dpre_seq = bf ? take_bytes(2 * BT * 4 * H) : take(BT * 4 * H);
+        p->dx_seq = take(BT * H); p->dpre_tsum = take((size_t)B * 4 * H);
         size_t gp = 0;
         auto upd = [&](int R, int M, int N) { const size_t e = gemm_tn_partial_elems(R, M, N); if (e > gp) gp = e; };
         upd((int)BT, H, D); upd((int)BT, 4 * H, H); upd((int)BT, 4 * H, D); upd(B, 4 * H, H); upd(B, H, Z); upd(B, Z, H);
+        if (bf) { const size_t e = gemm_tn_bf16_partial_elems((int)BT, 4 * H, H); if (e > gp) gp = e; }
         p->gemm_partial_elems = gp;
         p->gemm_partial = take(gp > 0 ? gp : 1);
         size_t cs = colsum_scratch_elems((int)BT, D);
@@ -256,9 +272,18 @@ extern "C" int shm_vae_pack_weights(shm_vae_plan* p, const float* params, void* 
     for (int l = 0; l < L; ++l) {
         for (int st = 0; st < 2; ++st) {
             const LayerInst& li = st == 0 ? p->enc[l] : p->dec[l];
+            if ((rc = launch_bias_sum(params + li.b_ih, params + li.b_hh, 4 * H, at<float>(ws, li.bsum), s))) return rc;
+            if (p->cfg.precision == SHM_PREC_BF16) {
+                if ((rc = launch_pack_fwd_bf16(params + li.w_ih, H, li.In, at<bf16_t>(ws, li.Wx), s))) return rc;
+                if ((rc = launch_pack_fwd_bf16(params + li.w_hh, H, H, at<bf16_t>(ws, li.Wh), s))) return rc;
+                if (p->training) {
+                    if ((rc = launch_pack_bwd_bf16(params + li.w_hh, H, H, at<bf16_t>(ws, li.WhT), s))) return rc;
+                    if (l > 0 && (rc = launch_pack_bwd_bf16(params + li.w_ih, H, li.In, at<bf16_t>(ws, li.WxT), s))) return rc;
+                }
+                continue;
+            }
             if ((rc = launch_pack_fwd_f32(params + li.w_ih, H, li.In, at<float>(ws, li.Wx), s))) return rc;
             if ((rc = launch_pack_fwd_f32(params + li.w_hh, H, H, at<float>(ws, li.Wh), s))) return rc;
-            if ((rc = launch_bias_sum(params + li.b_ih, params + li.b_hh, 4 * H, at<float>(ws, li.bsum), s))) return rc;
             if (p->training) {
                 if ((rc = launch_pack_bwd_f32(params + li.w_hh, H, H, at<float>(ws, li.WhT), s))) return rc;
                 if (l > 0 && (rc = launch_pack_bwd_f32(params + li.w_ih, H, li.In, at<float>(ws, li.WxT), s))) return rc;
@@ -287,6 +312,25 @@ extern "C" int shm_vae_forward(shm_vae_plan* p, const float* x, const float* eps
 
     auto run_stack = [&](LayerInst* st, const float* in0, uint32_t stack, float* h_last) -> int {
         for (int l = 0; l < L; ++l) {
+            char nm[32];
+            snprintf(nm, sizeof(nm), "lstm_fwd.%s%d", stack == 0 ? "enc" : "dec", l);
+            if (c.precision == SHM_PREC_BF16) {
+                LstmFwdArgsB a;
+                memset(&a, 0, sizeof(a));
+                a.in = l == 0 ? (const void*)in0 : (const void*)at<bf16_t>(ws, st[l - 1].h_seq);
+                a.in_f32 = l == 0 ? 1 : 0;
+                a.Wx = at<bf16_t>(ws, st[l].Wx); a.Wh = at<bf16_t>(ws, st[l].Wh); a.bias = at<float>(ws, st[l].bsum);
+                a.h_seq = at<bf16_t>(ws, st[l].h_seq);
+                a.h_last = (l == L - 1) ? h_last : nullptr;
+                a.sv_g = save ? at<bf16_t>(ws, st[l].saved) : nullptr;
+                a.sv_c = save ? at<float>(ws, st[l].saved_c) : nullptr;
+                a.B = B; a.T = T; a.In = st[l].In; a.in_const = st[l].in_const ? 1 : 0;
+                a.drop_p = l > 0 ? drop : 0.f; a.drop_seed = drop_seed; a.drop_stack = stack;
+                KernelTimer kt(nm, s);
+                int r = launch_lstm_fwd_bf16(H, a, s);
+                if (r) return r;
+                continue;
+            }
             LstmFwdArgs a;
             memset(&a, 0, sizeof(a));
             a.in = l == 0 ? in0 : at<float>(ws, st[l - 1].h_seq);
@@ -296,8 +340,6 @@ extern "C" int shm_vae_forward(shm_vae_plan* p, const float* x, const float* eps
             a.saved = save ? at<float>(ws, st[l].saved) : nullptr;
             a.B = B; a.T = T; a.In = st[l].In; a.in_const = st[l].in_const ? 1 : 0;
             a.drop_p = l > 0 ? drop : 0.f; a.drop_seed = drop_seed; a.drop_stack = stack;
-            char nm[32];
-            snprintf(nm, sizeof(nm), "lstm_fwd.%s%d", stack == 0 ? "enc" : "dec", l);
             KernelTimer kt(nm, s);
             int r = launch_lstm_fwd_f32(H, a, s);
             if (r) return r;
@@ -315,7 +357,7 @@ extern "C" int shm_vae_forward(shm_vae_plan* p, const float* x, const float* eps
     float* rec = recon ? recon : (p->training ? at<float>(ws, p->recon) : nullptr);
     {
         KernelTimer kt("out_fwd", s);
-        if ((rc = launch_out_fwd(B, T, D, H, at<float>(ws, p->dec[L - 1].h_seq), prm + p->out_w, prm + p->out_b, x, rec,
+        if ((rc = launch_out_fwd(B, T, D, H, at<char>(ws, p->dec[L - 1].h_seq), c.precision == SHM_PREC_BF16, prm + p->out_w, prm + p->out_b, x, rec,
                                  at<float>(ws, p->score), s))) return rc;
     }
     if (score) SHM_HIP_CHECK(hipMemcpyAsync(score, at<float>(ws, p->score), sizeof(float) * B, hipMemcpyDeviceToDevice, s));
@@ -353,16 +395,28 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
     const int BT = B * T, G = 4 * H;
     const float drop = p->drop_active ? c.dropout : 0.f;
     const float* prm = at<float>(ws, p->params_copy);
-    float* dpre_seq = at<float>(ws, p->dpre_seq);
+    float* dpre_seq = at<float>(ws, p->dpre_seq);          // fp32 view (fp32 path only)
     float* dx_seq = at<float>(ws, p->dx_seq);
     float* dpre_tsum = at<float>(ws, p->dpre_tsum);
     float* cs = at<float>(ws, p->colsum_scratch);
     const HeadBufs hb = head_bufs(p, ws);
 
-    auto gemm = [&](const float* A, int lda, int M, const float* Bm, int ldb, int N, int R, float* C, int shift_T, int trans_out,
-                    float dp, uint32_t stack) -> int {
+    const bool bf = c.precision == SHM_PREC_BF16;
+    // wide products on bf16 operands (A = dpre_seq, B = an h sequence): bf16 MFMA GEMM
+    auto gemm_bf = [&](const void* A, int lda, int M, const void* Bm, int ldb, int N, int R, float* C, int shift_T, float dp,
+                       uint32_t stack) -> int {
+        GemmTnArgsB g;
+        memset(&g, 0, sizeof(g));
+        g.A = A; g.lda = lda; g.Bm = Bm; g.ldb = ldb; g.b_f32 = 0; g.C = C; g.R = R; g.M = M; g.N = N; g.shift_T = shift_T;
+        g.drop_p = dp; g.drop_seed = p->drop_seed; g.drop_stack = stack;
+        g.partial = at<float>(ws, p->gemm_partial); g.partial_elems = p->gemm_partial_elems;
+        return launch_gemm_tn_bf16(g, s);
+    };
+    auto gemm = [&](const void* A, int lda, int M, const void* Bm, int ldb, int N, int R, float* C, int shift_T, int trans_out,
+                    float dp, uint32_t stack, int a_bf16 = 0, int b_bf16 = 0) -> int {
         GemmTnArgs g;
         memset(&g, 0, sizeof(g));
+        g.a_bf16 = a_bf16; g.b_bf16 = b_bf16;
         g.A = A; g.lda = lda; g.Bm = Bm; g.ldb = ldb; g.C = C; g.ldc = trans_out ? M : N; g.R = R; g.M = M; g.N = N;
         g.shift_T = shift_T; g.trans_out = trans_out; g.drop_p = dp; g.drop_seed = p->drop_seed; g.drop_stack = stack;
         g.partial = at<float>(ws, p->gemm_partial); g.partial_elems = p->gemm_partial_elems;
@@ -370,15 +424,53 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
     };
 
     // output layer (temporal_vae.py:70): dW_out[d][k] = sum_r d_recon[r][d] h[r][k]
-    const float* h_top = at<float>(ws, p->dec[L - 1].h_seq);
+    const void* h_top = at<char>(ws, p->dec[L - 1].h_seq);
     {
         KernelTimer kt("dw_gemm.out", s);
-        if ((rc = gemm(h_top, H, H, d_recon, D, D, BT, grads + p->out_w, 0, 1, 0.f, 0))) return rc;
+        if ((rc = gemm(h_top, H, H, d_recon, D, D, BT, grads + p->out_w, 0, 1, 0.f, 0, bf ? 1 : 0, 0))) return rc;
         if ((rc = launch_colsum(d_recon, D, BT, D, grads + p->out_b, nullptr, cs, s))) return rc;
     }
 
     auto run_stack_bwd = [&](LayerInst* st, uint32_t stack, const float* x0, bool is_dec) -> int {
         for (int l = L - 1; l >= 0; --l) {
+            char nm[32], gnm[32];
+            snprintf(nm, sizeof(nm), "lstm_bwd.%s%d", stack == 0 ? "enc" : "dec", l);
+            snprintf(gnm, sizeof(gnm), "dw_gemm.%s%d", stack == 0 ? "enc" : "dec", l);
+            if (bf) {
+                LstmBwdArgsB a;
+                memset(&a, 0, sizeof(a));
+                a.sv_g = at<bf16_t>(ws, st[l].saved); a.sv_c = at<float>(ws, st[l].saved_c);
+                if (l == L - 1) {
+                    if (is_dec) { a.dy = d_recon; a.Wout = prm + p->out_w; a.Dy = D; }
+                    else a.dh_last = hb.dh_last;
+                } else {
+                    a.dh_seq = dx_seq;
+                }
+                a.WhT = at<bf16_t>(ws, st[l].WhT);
+                a.need_dx = l > 0 ? 1 : 0;
+                a.WxT = l > 0 ? at<bf16_t>(ws, st[l].WxT) : nullptr;
+                a.dpre_seq = at<bf16_t>(ws, p->dpre_seq); a.dpre_tsum = dpre_tsum; a.dx_seq = dx_seq;
+                a.B = B; a.T = T; a.In = st[l].In;
+                a.drop_p = l > 0 ? drop : 0.f; a.drop_seed = p->drop_seed; a.drop_stack = stack;
+                int r;
+                {
+                    KernelTimer kt(nm, s);
+                    r = launch_lstm_bwd_bf16(H, a, s);
+                }
+                if (r) return r;
+                KernelTimer kt(gnm, s);
+                const void* dps = at<char>(ws, p->dpre_seq);
+                if ((r = gemm_bf(dps, G, G, at<char>(ws, st[l].h_seq), H, H, BT, grads + st[l].w_hh, T, 0.f, 0))) return r;
+                if (l > 0) {
+                    if ((r = gemm_bf(dps, G, G, at<char>(ws, st[l - 1].h_seq), H, H, BT, grads + st[l].w_ih, 0, drop, stack))) return r;
+                } else if (st[l].in_const) {
+                    if ((r = gemm(dpre_tsum, G, G, hb.h0, H, H, B, grads + st[l].w_ih, 0, 0, 0.f, 0))) return r;
+                } else {
+                    if ((r = gemm(dps, G, G, x0, D, D, BT, grads + st[l].w_ih, 0, 0, 0.f, 0, 1, 0))) return r;
+                }
+                if ((r = launch_colsum(dpre_tsum, G, B, G, grads + st[l].b_ih, grads + st[l].b_hh, cs, s))) return r;
+                continue;
+            }
             LstmBwdArgs a;
             memset(&a, 0, sizeof(a));
             a.saved = at<float>(ws, st[l].saved);
@@ -396,14 +488,10 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
             a.drop_p = l > 0 ? drop : 0.f; a.drop_seed = p->drop_seed; a.drop_stack = stack;
             int r;
             {
-                char nm[32];
-                snprintf(nm, sizeof(nm), "lstm_bwd.%s%d", stack == 0 ? "enc" : "dec", l);
                 KernelTimer kt(nm, s);
                 r = launch_lstm_bwd_f32(H, a, s);
             }
             if (r) return r;
-            char gnm[32];
-            snprintf(gnm, sizeof(gnm), "dw_gemm.%s%d", stack == 0 ? "enc" : "dec", l);
             KernelTimer kt(gnm, s);
             // deferred weight gradients of this layer
             if ((r = gemm(dpre_seq, G, G, at<float>(ws, st[l].h_seq), H, H, BT, grads + st[l].w_hh, T, 0, 0.f, 0))) return r;

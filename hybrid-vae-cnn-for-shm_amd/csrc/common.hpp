@@ -30,7 +30,11 @@ void set_error(const char* fmt, ...);
 
 // ---------------------------------------------------------------- MFMA wrappers (gfx950)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // D[16x16] += A[16x4] * B[4x16], exact f32 (v_mfma_f32_16x16x4_f32).
 // lane l supplies A[row = l&15][k = l>>4] and B[k = l>>4][col = l&15]; holds D[row = 4*(l>>4)+r][col = l&15], r = 0..3.
@@ -43,12 +47,15 @@ __device__ __forceinline__ f32x4 mfma_bf16_16x16x32(bf16x8 a, bf16x8 b, f32x4 c)
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-__device__ __forceinline__ unsigned short f32_to_bf16(float f) {   // round-to-nearest-even; NaN stays NaN
-    unsigned int u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-}
-__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
+// f32 -> bf16 by plain casts: hipcc emits v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN stays NaN)
+__device__ __forceinline__ bf16x4 cvt_bf16x4(f32x4 v) { return __builtin_convertvector(v, bf16x4); }
+__device__ __forceinline__ f32x4 cvt_f32x4(bf16x4 v) { return __builtin_convertvector(v, f32x4); }
+
+// LDS image of a [16 windows][K] bf16 operand tile, quarter-major: element (j,k) lives at
+//   ((k / KQ) * 16 + j) * RS + (k % KQ),   RS = KQ + pad  with RS*2/16 odd
+// so that the 16 lanes of every ds_read_b128 group (fixed k-step, 16 windows across two quarters) hit 16 distinct
+// 16-byte slots of the 256-byte bank row: conflict-free operand reads.
+__host__ __device__ constexpr int lds_row_stride(int KQ) { return KQ + ((KQ / 8) % 2 == 0 ? 8 : 16); }
 
 // ---------------------------------------------------------------- activation math
 // Parity path (fp32): ocml expf/tanhf and IEEE division.

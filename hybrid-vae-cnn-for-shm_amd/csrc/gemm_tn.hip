@@ -16,8 +16,10 @@ namespace {
 constexpr int KC = 32;        // contraction rows staged per iteration
 
 // 4 waves arranged WAVES_M x WAVES_N; each wave computes WMT x WNT tiles of 16x16.
-template <int WMT, int WNT, int WAVES_M, int WAVES_N>
+template <int WMT, int WNT, int WAVES_M, int WAVES_N, typename TA, typename TB>
 __global__ void __launch_bounds__(256) gemm_tn_f32_kernel(GemmTnArgs a, int tiles_n, int rows_per_split, int nsplit) {
+    const TA* Ap = reinterpret_cast<const TA*>(a.A);
+    const TB* Bp = reinterpret_cast<const TB*>(a.Bm);
     constexpr int MT = 16 * WMT * WAVES_M, NT = 16 * WNT * WAVES_N;
     constexpr int LDA = MT + 16, LDB = NT + 16 + (((NT + 16) % 32) == 0 ? 16 : 0);   // row stride % 32 == 16: b32 reads conflict-free
     __shared__ float sA[KC][LDA];
@@ -45,16 +47,16 @@ __global__ void __launch_bounds__(256) gemm_tn_f32_kernel(GemmTnArgs a, int tile
         // ---- stage A[r0..r0+KC) x [m0..m0+MT) and B likewise (element-guarded; rows are contiguous in memory)
         for (int e = tid; e < KC * MT; e += 256) {
             const int kk = e / MT, mm = e - kk * MT, r = r0 + kk, m = m0 + mm;
-            sA[kk][mm] = (r < r_end && m < a.M) ? a.A[(size_t)r * a.lda + m] : 0.f;
+            sA[kk][mm] = (r < r_end && m < a.M) ? (float)Ap[(size_t)r * a.lda + m] : 0.f;
         }
         for (int e = tid; e < KC * NT; e += 256) {
             const int kk = e / NT, nn = e - kk * NT, r = r0 + kk, n = n0 + nn;
             float v = 0.f;
             if (r < r_end && n < a.N) {
                 if (a.shift_T > 0) {
-                    if (r % a.shift_T != 0) v = a.Bm[(size_t)(r - 1) * a.ldb + n];
+                    if (r % a.shift_T != 0) v = (float)Bp[(size_t)(r - 1) * a.ldb + n];
                 } else {
-                    v = a.Bm[(size_t)r * a.ldb + n];
+                    v = (float)Bp[(size_t)r * a.ldb + n];
                     if (drop) v = drop_hash(a.drop_seed, a.drop_stack, (uint32_t)((size_t)r * a.N + n)) >= thr ? v * dscale : 0.f;
                 }
             }
@@ -132,10 +134,18 @@ int launch_gemm_tn_f32(const GemmTnArgs& a, hipStream_t s) {
                 "gemm_tn: split-K scratch too small");
     SHM_REQUIRE(a.ldc == (a.trans_out ? a.M : a.N) || g.nsplit == 1, SHM_EINVAL, "gemm_tn: split-K needs a dense output");
     dim3 grid(g.tiles_m * g.tiles_n, g.nsplit);
-    if (g.narrow)
-        hipLaunchKernelGGL((gemm_tn_f32_kernel<1, 1, 4, 1>), grid, dim3(256), 0, s, a, g.tiles_n, g.rows_per_split, g.nsplit);
-    else
-        hipLaunchKernelGGL((gemm_tn_f32_kernel<2, 2, 2, 2>), grid, dim3(256), 0, s, a, g.tiles_n, g.rows_per_split, g.nsplit);
+#define SHM_GEMM_LAUNCH(TA, TB)                                                                                              \
+    do {                                                                                                                     \
+        if (g.narrow)                                                                                                        \
+            hipLaunchKernelGGL((gemm_tn_f32_kernel<1, 1, 4, 1, TA, TB>), grid, dim3(256), 0, s, a, g.tiles_n, g.rows_per_split, g.nsplit); \
+        else                                                                                                                 \
+            hipLaunchKernelGGL((gemm_tn_f32_kernel<2, 2, 2, 2, TA, TB>), grid, dim3(256), 0, s, a, g.tiles_n, g.rows_per_split, g.nsplit); \
+    } while (0)
+    if (a.a_bf16 && a.b_bf16) SHM_GEMM_LAUNCH(bf16_t, bf16_t);
+    else if (a.a_bf16) SHM_GEMM_LAUNCH(bf16_t, float);
+    else if (a.b_bf16) SHM_GEMM_LAUNCH(float, bf16_t);
+    else SHM_GEMM_LAUNCH(float, float);
+#undef SHM_GEMM_LAUNCH
     SHM_LAUNCH_CHECK();
     if (g.nsplit > 1) return launch_reduce_partials(a.partial, g.nsplit, (size_t)a.M * a.N, a.C, nullptr, s);
     return SHM_OK;

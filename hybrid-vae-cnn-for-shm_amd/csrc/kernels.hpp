@@ -60,15 +60,16 @@ int launch_head_bwd(int B, int H, int Z, int layer_norm, const float* dpre_tsum,
                     hipStream_t s);
 
 // ---- output layer + per-window score; loss --------------------------------------------------------------
-int launch_out_fwd(int B, int T, int D, int H, const float* h_seq, const float* Wout, const float* bout,
+int launch_out_fwd(int B, int T, int D, int H, const void* h_seq, int h_bf16, const float* Wout, const float* bout,
                    const float* x, float* recon, float* score, hipStream_t s);
 int launch_vae_loss(int B, int T, int D, int Z, const float* x, const float* recon, const float* mu, const float* lv,
                     float kl_w, float* d_recon, float* d_mu, float* d_lv, float* score, float* losses, hipStream_t s);
 
 // ---- C[M,N] (+)= sum_r A[r,M]^T B[r,N]  (weight gradients), fp32 MFMA, deterministic split-K ----------------
 struct GemmTnArgs {
-    const float* A; int lda;       // [R, M]
-    const float* Bm; int ldb;      // [R, N]
+    const void* A; int lda;        // [R, M] fp32, or bf16 when a_bf16
+    const void* Bm; int ldb;       // [R, N] fp32, or bf16 when b_bf16
+    int a_bf16, b_bf16;
     float* C; int ldc;             // [M, N] row-major (or transposed when trans_out)
     int R, M, N;
     int shift_T;                   // >0: B row r is taken from row r-1, zero when r % shift_T == 0  (h_{t-1})
@@ -84,6 +85,54 @@ int launch_colsum(const float* A, int lda, int R, int N, float* out0, float* out
 size_t colsum_scratch_elems(int R, int N);
 // out[i] (and out1[i]) = sum_p partial[p*n + i], p < nparts (fixed order)
 int launch_reduce_partials(const float* partial, int nparts, size_t n, float* out0, float* out1, hipStream_t s);
+
+// ==== bf16 throughput path (fp32 accumulate / cell state / master weights) ===================================
+// Packed forward operand (bf16): Kpad = round_up(K,32), KQ = Kpad/4, KS = KQ/8 k-steps of 32
+//   packed[((ht*KS + s)*4 + g)*64 + lane][e] = W[g*H + ht*16 + (lane&15)][(lane>>4)*KQ + 8*s + e], e = 0..7
+// Packed backward operand (bf16, W^T): KS = H/8 k-steps over K = 4H (lane quarter q <-> gate q)
+//   packed[(mt*KS + s)*64 + lane][e] = W[(lane>>4)*H + 8*s + e][mt*16 + (lane&15)]
+inline size_t fwd_pack_elems_bf16(int H, int K) { return (size_t)4 * H * round_up(K, 32); }
+inline size_t bwd_pack_elems_bf16(int H, int M) { return (size_t)round_up(M, 16) * 4 * H; }
+
+struct LstmFwdArgsB {
+    const void* in;         // fp32 [B,T,In] (encoder layer 0), fp32 [B,H] (in_const) or bf16 [B,T,H]
+    const bf16_t* Wx; const bf16_t* Wh;
+    const float* bias;
+    bf16_t* h_seq;          // [B,T,H] bf16
+    float* h_last;          // [B,H] fp32 or nullptr
+    bf16_t* sv_g;           // [tile][T][H/16][64][16] gates i,f,g,o (bf16) or nullptr
+    float* sv_c;            // [tile][T][H/16][64][4]  cell state (fp32)
+    int B, T, In, in_const, in_f32;
+    float drop_p; uint64_t drop_seed; uint32_t drop_stack;
+};
+int launch_lstm_fwd_bf16(int H, const LstmFwdArgsB& a, hipStream_t s);
+
+struct LstmBwdArgsB {
+    const bf16_t* sv_g; const float* sv_c;
+    const float* dh_seq; const float* dy; const float* Wout; const float* dh_last;
+    const bf16_t* WhT; const bf16_t* WxT;
+    bf16_t* dpre_seq;       // [B,T,4H] bf16
+    float* dpre_tsum;       // [B,4H] fp32
+    float* dx_seq;          // [B,T,In] fp32
+    int B, T, In, Dy, need_dx;
+    float drop_p; uint64_t drop_seed; uint32_t drop_stack;
+};
+int launch_lstm_bwd_bf16(int H, const LstmBwdArgsB& a, hipStream_t s);
+
+struct GemmTnArgsB {
+    const void* A; int lda;        // [R, M] bf16
+    const void* Bm; int ldb;       // [R, N] bf16 or fp32 (b_f32)
+    int b_f32;
+    float* C;                      // [M, N] dense
+    int R, M, N, shift_T;
+    float drop_p; uint64_t drop_seed; uint32_t drop_stack;
+    float* partial; size_t partial_elems;
+};
+int launch_gemm_tn_bf16(const GemmTnArgsB& a, hipStream_t s);
+size_t gemm_tn_bf16_partial_elems(int R, int M, int N);
+
+int launch_pack_fwd_bf16(const float* W, int H, int K, bf16_t* dst, hipStream_t s);
+int launch_pack_bwd_bf16(const float* W, int H, int M, bf16_t* dst, hipStream_t s);
 
 // ---- weight packing -----------------------------------------------------------------------------------------
 int launch_pack_fwd_f32(const float* W, int H, int K, float* dst, hipStream_t s);

@@ -1,0 +1,225 @@
+// lstm_fwd_bf16.hip — persistent LSTM layer forward, bf16 MFMA (v_mfma_f32_16x16x32_bf16), fp32 accumulate and
+// fp32 cell state; gfx950.  Throughput twin of lstm_fwd.hip (same ownership: workgroup = 16 windows, wave w = hidden
+// units [16w,16w+16) x gates i,f,g,o, lane (q,j) = units 16w+4q+r of window j), replacing the nn.LSTM cell loop of
+// reference 4DOF/Scripts/Models/temporal_vae.py:53,69.
+//
+// What changes against the fp32 kernel:
+//   * W_hh and W_ih live in REGISTERS for the whole sequence (64 VGPRs per matrix per wave at H=128) — the time loop
+//     touches no weight memory at all;
+//   * h_t returns to LDS as bf16 in a quarter-major, conflict-free image (common.hpp: lds_row_stride);
+//   * sigmoid/tanh use v_exp_f32 / v_rcp_f32;
+//   * saved state for BPTT: gates as bf16 (32 B/lane/step), c as fp32 (16 B/lane/step), both in fragment order.
+#include "kernels.hpp"
+
+namespace shm {
+
+namespace {
+
+// XK: k-steps (of 32) of the input operand.  XF32: dynamic input is fp32 [B,T,In] with In <= 32 (encoder layer 0).
+template <int H, int XK, bool XF32, bool DROP>
+__global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
+    constexpr int NW = H / 16, NTHR = 64 * NW;
+    constexpr int KSH = H / 32;                 // k-steps of the recurrent operand
+    constexpr int KQH = H / 4, RSH = lds_row_stride(KQH);
+    constexpr int KQX = XK * 8, RSX = lds_row_stride(KQX);
+    constexpr int HBUF = 4 * 16 * RSH, XBUF = 4 * 16 * RSX;       // elements per buffer
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem_b[];
+    bf16_t* h_lds = smem_b;                     // [2][HBUF]
+    bf16_t* x_lds = smem_b + 2 * HBUF;          // [2][XBUF]
+
+    const int In = a.In, T = a.T, B = a.B;
+    const int tid = threadIdx.x, lane = tid & 63, ht = tid >> 6, q = lane >> 4, j = lane & 15;
+    const int tile = blockIdx.x, b0 = tile * 16, b = b0 + j;
+    const bool bvalid = b < B;
+    const int u0 = ht * 16 + q * 4;
+
+    for (int e = tid; e < 2 * (HBUF + XBUF); e += NTHR) smem_b[e] = (bf16_t)0.f;
+
+    // ---- weights -> registers (fragment order, see kernels.hpp)
+    bf16x8 wh[4][KSH], wx[4][XK];
+    {
+        const bf16x8* p = reinterpret_cast<const bf16x8*>(a.Wh) + (size_t)ht * KSH * 4 * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < KSH; ++s)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) wh[g][s] = p[(s * 4 + g) * 64];
+        const bf16x8* px = reinterpret_cast<const bf16x8*>(a.Wx) + (size_t)ht * XK * 4 * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < XK; ++s)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) wx[g][s] = px[(s * 4 + g) * 64];
+    }
+    f32x4 bias4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias4[g] = *reinterpret_cast<const f32x4*>(a.bias + g * H + u0);
+
+    const uint32_t thr = drop_threshold(a.drop_p);
+    const float dscale = DROP ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+
+    // my slot in the operand images: (window j, units u0..u0+3)
+    const int my_h_off = ((u0 / KQH) * 16 + j) * RSH + (u0 % KQH);
+    const int my_x_off = ((u0 / KQX) * 16 + j) * RSX + (u0 % KQX);      // only meaningful when In == H
+
+    // ---- x staging
+    bf16x4 xr = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+    float xs[2] = {0.f, 0.f};             // XF32 path: <= 2 scalars per thread (16*In <= 2*NTHR, checked on host)
+    auto x_load = [&](int t) {
+        if constexpr (XF32) {
+            const float* xin = reinterpret_cast<const float*>(a.in);
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int e = tid + it * NTHR;
+                xs[it] = 0.f;
+                if (e < 16 * In) {
+                    const int jj = e / In, kk = e - jj * In, bb = b0 + jj;
+                    if (bb < B) xs[it] = xin[((size_t)bb * T + t) * In + kk];
+                }
+            }
+        } else {
+            const bf16_t* xin = reinterpret_cast<const bf16_t*>(a.in);
+            if (bvalid) {
+                const size_t idx = ((size_t)b * T + t) * H + u0;
+                xr = *reinterpret_cast<const bf16x4*>(xin + idx);
+                if (DROP) {
+                    f32x4 v = cvt_f32x4(xr);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        v[e] = drop_hash(a.drop_seed, a.drop_stack, (uint32_t)(idx + e)) >= thr ? v[e] * dscale : 0.f;
+                    xr = cvt_bf16x4(v);
+                }
+            }
+        }
+    };
+    auto x_store = [&](int buf) {
+        bf16_t* xl = x_lds + buf * XBUF;
+        if constexpr (XF32) {
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int e = tid + it * NTHR;
+                if (e < 16 * In) {
+                    const int jj = e / In, kk = e - jj * In;
+                    xl[((kk / KQX) * 16 + jj) * RSX + (kk % KQX)] = (bf16_t)xs[it];
+                }
+            }
+        } else {
+            *reinterpret_cast<bf16x4*>(xl + my_x_off) = xr;
+        }
+    };
+
+    auto mma_h = [&](f32x4 (&acc)[4], const bf16_t* img) {
+        const bf16_t* row = img + (q * 16 + j) * RSH;
+#pragma unroll
+        for (int s = 0; s < KSH; ++s) {
+            const bf16x8 bv = *reinterpret_cast<const bf16x8*>(row + 8 * s);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = mfma_bf16_16x16x32(wh[g][s], bv, acc[g]);
+        }
+    };
+    auto mma_x = [&](f32x4 (&acc)[4], const bf16_t* img) {
+        const bf16_t* row = img + (q * 16 + j) * RSX;
+#pragma unroll
+        for (int s = 0; s < XK; ++s) {
+            const bf16x8 bv = *reinterpret_cast<const bf16x8*>(row + 8 * s);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = mfma_bf16_16x16x32(wx[g][s], bv, acc[g]);
+        }
+    };
+
+    __syncthreads();
+    f32x4 xproj[4];
+    if (a.in_const) {
+        // decoder layer 0: the same h0 at every step (temporal_vae.py:68) -> project once, keep in registers
+        const float* h0 = reinterpret_cast<const float*>(a.in);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (bvalid) v = *reinterpret_cast<const f32x4*>(h0 + (size_t)b * H + u0);
+        *reinterpret_cast<bf16x4*>(x_lds + my_x_off) = cvt_bf16x4(v);
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xproj[g] = bias4[g];
+        mma_x(xproj, x_lds);
+    } else {
+        x_load(0);
+        x_store(0);
+        __syncthreads();
+    }
+
+    f32x4 c = {0.f, 0.f, 0.f, 0.f}, h4 = {0.f, 0.f, 0.f, 0.f};
+    bf16_t* svg = a.sv_g ? a.sv_g + (((size_t)tile * T * NW + ht) * 64 + lane) * 16 : nullptr;
+    float* svc = a.sv_c ? a.sv_c + (((size_t)tile * T * NW + ht) * 64 + lane) * 4 : nullptr;
+
+    for (int t = 0; t < T; ++t) {
+        const int cur = t & 1;
+        if (!a.in_const && t + 1 < T) x_load(t + 1);
+        f32x4 acc[4];
+        if (a.in_const) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = xproj[g];
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = bias4[g];
+            mma_x(acc, x_lds + cur * XBUF);
+        }
+        mma_h(acc, h_lds + cur * HBUF);
+
+        f32x4 gi, gf, gg, go;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            gi[r] = sigmoid_fast(acc[0][r]);
+            gf[r] = sigmoid_fast(acc[1][r]);
+            gg[r] = tanh_fast(acc[2][r]);
+            go[r] = sigmoid_fast(acc[3][r]);
+            c[r] = gf[r] * c[r] + gi[r] * gg[r];
+            h4[r] = go[r] * tanh_fast(c[r]);
+        }
+        const bf16x4 hb = cvt_bf16x4(h4);
+        *reinterpret_cast<bf16x4*>(h_lds + (cur ^ 1) * HBUF + my_h_off) = hb;
+        if (!a.in_const && t + 1 < T) x_store(cur ^ 1);
+        if (a.h_seq && bvalid) *reinterpret_cast<bf16x4*>(a.h_seq + ((size_t)b * T + t) * H + u0) = hb;
+        if (svg) {
+            bf16_t* p = svg + (size_t)t * NW * 64 * 16;
+            bf16x8 lo, hi;
+            const bf16x4 bi = cvt_bf16x4(gi), bf = cvt_bf16x4(gf), bg = cvt_bf16x4(gg), bo = cvt_bf16x4(go);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { lo[r] = bi[r]; lo[4 + r] = bf[r]; hi[r] = bg[r]; hi[4 + r] = bo[r]; }
+            *reinterpret_cast<bf16x8*>(p) = lo;
+            *reinterpret_cast<bf16x8*>(p + 8) = hi;
+            *reinterpret_cast<f32x4*>(svc + (size_t)t * NW * 64 * 4) = c;
+        }
+        __syncthreads();
+    }
+    if (a.h_last && bvalid) *reinterpret_cast<f32x4*>(a.h_last + (size_t)b * H + u0) = h4;
+}
+
+template <int H, int XK, bool XF32>
+int launch_x(const LstmFwdArgsB& a, hipStream_t s) {
+    const int tiles = ceil_div(a.B, 16);
+    const size_t lds = sizeof(bf16_t) * 2 * 4 * 16 * (lds_row_stride(H / 4) + lds_row_stride(XK * 8));
+    auto kern = (a.drop_p > 0.f) ? lstm_fwd_bf16_kernel<H, XK, XF32, true> : lstm_fwd_bf16_kernel<H, XK, XF32, false>;
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(4 * H), lds, s, a);
+    SHM_LAUNCH_CHECK();
+    return SHM_OK;
+}
+
+template <int H>
+int launch_h(const LstmFwdArgsB& a, hipStream_t s) {
+    if (a.in_f32 && !a.in_const) {
+        SHM_REQUIRE(a.In <= 32 && 16 * a.In <= 8 * H, SHM_EINVAL, "lstm_fwd_bf16: fp32 input width %d too wide for H=%d", a.In, H);
+        return launch_x<H, 1, true>(a, s);
+    }
+    SHM_REQUIRE(a.In == H, SHM_EINVAL, "lstm_fwd_bf16: layer input width %d must equal hidden width %d", a.In, H);
+    return launch_x<H, H / 32, false>(a, s);
+}
+
+}  // namespace
+
+int launch_lstm_fwd_bf16(int H, const LstmFwdArgsB& a, hipStream_t s) {
+    SHM_REQUIRE(a.B > 0 && a.T > 0 && a.In > 0, SHM_EINVAL, "lstm_fwd_bf16: empty shape");
+    switch (H) {
+        case 32: return launch_h<32>(a, s);
+        case 64: return launch_h<64>(a, s);
+        case 128: return launch_h<128>(a, s);
+        default: set_error("lstm_fwd_bf16: hidden_dim %d unsupported (32, 64, 128)", H); return SHM_EINVAL;
+    }
+}
+
+}  // namespace shm

@@ -153,7 +153,8 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(int B, int H, int Z, int 
 
 // ------------------------------------------------------------------------------------------------ output layer + score
 constexpr int DMAX = 16;
-__global__ void __launch_bounds__(256) out_fwd_kernel(int T, int D, int H, const float* __restrict__ h_seq,
+template <typename TH>
+__global__ void __launch_bounds__(256) out_fwd_kernel(int T, int D, int H, const TH* __restrict__ h_seq,
                                                       const float* __restrict__ Wout, const float* __restrict__ bout,
                                                       const float* __restrict__ x, float* __restrict__ recon,
                                                       float* __restrict__ score) {
@@ -170,10 +171,10 @@ __global__ void __launch_bounds__(256) out_fwd_kernel(int T, int D, int H, const
     const float bias = lane < D ? bout[lane] : 0.f;
     float sq = 0.f;
     for (int t = w; t < T; t += 4) {
-        const float* h = h_seq + ((size_t)b * T + t) * H;
+        const TH* h = h_seq + ((size_t)b * T + t) * H;
         float hv[HMAX / 64];
 #pragma unroll
-        for (int i = 0; i < HMAX / 64; ++i) { const int k = lane + 64 * i; hv[i] = k < H ? h[k] : 0.f; }
+        for (int i = 0; i < HMAX / 64; ++i) { const int k = lane + 64 * i; hv[i] = k < H ? (float)h[k] : 0.f; }
         float mine = 0.f;
 #pragma unroll
         for (int d = 0; d < DMAX; ++d) {
@@ -282,6 +283,29 @@ __global__ void __launch_bounds__(256) pack_bwd_f32_kernel(const float* __restri
         dst[i] = m < M ? W[(size_t)k * M + m] : 0.f;
     }
 }
+__global__ void __launch_bounds__(256) pack_fwd_bf16_kernel(const float* __restrict__ W, int H, int K, bf16_t* __restrict__ dst) {
+    const int Kp = (K + 31) & ~31, KQ = Kp >> 2, KS = KQ >> 3;
+    const size_t n = (size_t)4 * H * Kp;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int e = i & 7, lane = (i >> 3) & 63;
+        size_t r = i >> 9;
+        const int g = r & 3; r >>= 2;
+        const int s = r % KS, ht = r / KS;
+        const int row = g * H + ht * 16 + (lane & 15), k = (lane >> 4) * KQ + 8 * s + e;
+        dst[i] = (bf16_t)(k < K ? W[(size_t)row * K + k] : 0.f);
+    }
+}
+__global__ void __launch_bounds__(256) pack_bwd_bf16_kernel(const float* __restrict__ W, int H, int M, bf16_t* __restrict__ dst) {
+    const int KS = H >> 3, Mp = (M + 15) & ~15;
+    const size_t n = (size_t)Mp * 4 * H;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int e = i & 7, lane = (i >> 3) & 63;
+        const size_t r = i >> 9;
+        const int s = r % KS, mt = r / KS;
+        const int k = (lane >> 4) * H + 8 * s + e, m = mt * 16 + (lane & 15);
+        dst[i] = (bf16_t)(m < M ? W[(size_t)k * M + m] : 0.f);
+    }
+}
 __global__ void __launch_bounds__(256) bias_sum_kernel(const float* __restrict__ a, const float* __restrict__ b, int n, float* __restrict__ dst) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) dst[i] = a[i] + b[i];
@@ -303,10 +327,13 @@ int launch_head_bwd(int B, int H, int Z, int layer_norm, const float* dpre_tsum,
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
-int launch_out_fwd(int B, int T, int D, int H, const float* h_seq, const float* Wout, const float* bout, const float* x,
+int launch_out_fwd(int B, int T, int D, int H, const void* h_seq, int h_bf16, const float* Wout, const float* bout, const float* x,
                    float* recon, float* score, hipStream_t s) {
     SHM_REQUIRE(D <= DMAX && H <= HMAX, SHM_EINVAL, "out: D=%d (<=%d) H=%d unsupported", D, DMAX, H);
-    hipLaunchKernelGGL(out_fwd_kernel, dim3(B), dim3(256), 0, s, T, D, H, h_seq, Wout, bout, x, recon, score);
+    if (h_bf16)
+        hipLaunchKernelGGL(out_fwd_kernel<bf16_t>, dim3(B), dim3(256), 0, s, T, D, H, (const bf16_t*)h_seq, Wout, bout, x, recon, score);
+    else
+        hipLaunchKernelGGL(out_fwd_kernel<float>, dim3(B), dim3(256), 0, s, T, D, H, (const float*)h_seq, Wout, bout, x, recon, score);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
@@ -339,6 +366,18 @@ int launch_pack_fwd_f32(const float* W, int H, int K, float* dst, hipStream_t s)
 int launch_pack_bwd_f32(const float* W, int H, int M, float* dst, hipStream_t s) {
     const size_t n = bwd_pack_elems(H, M);
     hipLaunchKernelGGL(pack_bwd_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, H, M, dst);
+    SHM_LAUNCH_CHECK();
+    return SHM_OK;
+}
+int launch_pack_fwd_bf16(const float* W, int H, int K, bf16_t* dst, hipStream_t s) {
+    const size_t n = fwd_pack_elems_bf16(H, K);
+    hipLaunchKernelGGL(pack_fwd_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, H, K, dst);
+    SHM_LAUNCH_CHECK();
+    return SHM_OK;
+}
+int launch_pack_bwd_bf16(const float* W, int H, int M, bf16_t* dst, hipStream_t s) {
+    const size_t n = bwd_pack_elems_bf16(H, M);
+    hipLaunchKernelGGL(pack_bwd_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, H, M, dst);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }

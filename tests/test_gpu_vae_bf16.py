@@ -1,0 +1,104 @@
+"""GPU tests of the bf16 throughput path (bf16 MFMA operands, fp32 accumulate / cell state / master weights).
+
+bf16 cannot meet the fp32 path's 1e-4 (rounding the weights alone to bf16 moves recon by 4.5e-4 on the
+reference module), so this path carries its own documented tolerances against the SAME reference goldens:
+  forward   recon, mu, logvar: abs <= 2e-2 ;  per-window score: rel <= 5e-3
+  training  loss: rel <= 2e-3 ; every gradient tensor: ||g - g_ref|| / ||g_ref|| <= 5e-2 ; grad-norm rel <= 2e-2
+The numbers printed by these tests are the measured values; DESIGN.md §5 quotes them.
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, split_prefix
+from test_gpu_vae import inject_eps, maxdiff
+
+pytestmark = pytest.mark.gpu
+
+
+def build_module(cfg, params, dropout=None):
+    from Scripts.Models.temporal_vae import TemporalVAE
+    m = TemporalVAE(cfg["input_dim"], cfg["latent_dim"], cfg["hidden_dim"], cfg["num_layers"],
+                    cfg["dropout"] if dropout is None else dropout, layer_norm=cfg["layer_norm"], precision="bf16")
+    m.load_state_dict({k: torch.tensor(v) for k, v in params.items()}, strict=True)
+    return m.cuda()
+
+
+@pytest.mark.parametrize("name", ["vae_fwd_mini", "vae_fwd_1dof", "vae_fwd_openlab", "vae_fwd_ref_h128", "vae_fwd_ns_h128"])
+def test_forward_bf16(name):
+    g = load_golden(name)
+    m = build_module(g["cfg"], split_prefix(g, "p.")).eval()
+    x = torch.tensor(g["x"]).cuda()
+    with torch.no_grad(), inject_eps([torch.tensor(g["eps"])]):
+        recon, mu, lv = m(x)
+    with inject_eps([torch.tensor(g["eps"])]):
+        score = m.score(x)
+    rel_score = float(np.abs(score.cpu().numpy() - g["score"]).max() / np.abs(g["score"]).max())
+    d = dict(recon=maxdiff(recon, g["recon"]), mu=maxdiff(mu, g["mu"]), logvar=maxdiff(lv, g["logvar"]), score_rel=rel_score)
+    print("bf16", name, json.dumps(d))
+    assert d["recon"] < 2e-2 and d["mu"] < 2e-2 and d["logvar"] < 2e-2 and rel_score < 5e-3, d
+
+
+@pytest.mark.parametrize("name", ["vae_train_mini", "vae_train_1dof", "vae_train_openlab", "vae_train_ns_h128"])
+def test_fused_trainer_bf16(name):
+    from shm_hip.trainer import VAETrainer
+    g = load_golden(name)
+    cfg = g["cfg"]
+    m = build_module(cfg, split_prefix(g, "p0."), dropout=0.0).train()
+    tr = VAETrainer(m, lr=cfg["lr"], weight_decay=cfg["wd"], max_norm=cfg["clip"])
+    x = torch.tensor(g["x0"]).cuda()
+    stats = tr.step(x, cfg["kl_w"], eps=torch.tensor(g["eps0"]).cuda()).cpu().numpy()
+    ref = g["loss0"]
+    grads = dict(zip([k for k, _, _ in tr.engine.layout], tr.engine.split(tr.grads)))
+    rep = {}
+    for k, v in split_prefix(g, "g0.").items():
+        gk = grads[k].cpu().numpy().astype(np.float64)
+        rep[k] = float(np.linalg.norm(gk - v) / max(np.linalg.norm(v), 1e-12))
+    print("bf16", name, "stats", stats.tolist(), "ref", ref.tolist())
+    print("bf16", name, "grad rel-L2", json.dumps({k: round(v, 5) for k, v in rep.items()}))
+    assert abs(stats[0] - ref[0]) < 2e-3 * max(1, abs(ref[0]))
+    assert abs(stats[3] - ref[3]) < 2e-2 * max(1, abs(ref[3]))
+    assert max(rep.values()) < 5e-2, rep
+
+
+def test_bf16_training_reduces_loss_like_fp32():
+    """Short optimisation run on structured synthetic windows: both precisions must descend to the same loss band."""
+    from Scripts.Models.temporal_vae import TemporalVAE
+    from shm_hip.trainer import VAETrainer
+    rng = np.random.default_rng(0)
+    t = np.arange(64)[None, :, None]
+    ph = rng.uniform(0, 6.28, (256, 1, 4)); fr = rng.uniform(0.05, 0.3, (256, 1, 4))
+    x = torch.tensor(np.sin(fr * t + ph).astype(np.float32)).cuda()
+    out = {}
+    for prec in ("fp32", "bf16"):
+        torch.manual_seed(3)
+        m = TemporalVAE(4, 8, 64, 2, 0.0, precision=prec).cuda().train()
+        tr = VAETrainer(m, lr=2e-3, weight_decay=0.0, max_norm=2.0, seed=5)
+        hist = []
+        for i in range(60):
+            hist.append(float(tr.step(x, 0.05)[0]))
+        out[prec] = hist
+    print("loss fp32 first/last", out["fp32"][0], out["fp32"][-1], "bf16 first/last", out["bf16"][0], out["bf16"][-1])
+    assert out["fp32"][-1] < 0.8 * out["fp32"][0]
+    assert abs(out["bf16"][-1] - out["fp32"][-1]) < 0.05 * out["fp32"][0]
+
+
+def test_bf16_full_size_properties():
+    from Scripts.Models.temporal_vae import TemporalVAE
+    torch.manual_seed(42)
+    m = TemporalVAE(4, 16, 128, 2, 0.3, precision="bf16").cuda().eval()
+    gen = torch.Generator().manual_seed(1)
+    x = torch.randn(512, 256, 4, generator=gen).cuda()
+    eps = torch.randn(512, 16, generator=gen)
+    with torch.no_grad():
+        with inject_eps([eps]):
+            r1, m1, l1 = m(x)
+        with inject_eps([eps]):
+            r2, m2, l2 = m(x)
+        with inject_eps([eps[:100]]):
+            r3, m3, l3 = m(x[:100])
+    assert torch.equal(r1, r2) and torch.equal(m1, m2)
+    assert torch.equal(r1[:100], r3) and torch.equal(m1[:100], m3)
+    assert torch.isfinite(r1).all()
