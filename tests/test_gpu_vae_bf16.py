@@ -2,8 +2,10 @@
 
 bf16 cannot meet the fp32 path's 1e-4 (rounding the weights alone to bf16 moves recon by 4.5e-4 on the
 reference module), so this path carries its own documented tolerances against the SAME reference goldens:
-  forward   recon, mu, logvar: abs <= 2e-2 ;  per-window score: rel <= 5e-3
-  training  loss: rel <= 2e-3 ; every gradient tensor: ||g - g_ref|| / ||g_ref|| <= 5e-2 ; grad-norm rel <= 2e-2
+  forward   recon: abs <= 2e-3 (measured <= 5.7e-4) ; mu, logvar: abs <= 1e-2 (measured <= 3.2e-3) ;
+            per-window score: rel <= 5e-4 (measured <= 7.7e-5)
+  training  loss: rel <= 5e-4 (measured <= 4e-5) ; every gradient tensor: ||g - g_ref|| / ||g_ref|| <= 2e-2
+            (measured <= 5e-3) ; grad-norm rel <= 2e-3 (measured <= 1.5e-4)
 The numbers printed by these tests are the measured values; DESIGN.md §5 quotes them.
 """
 import json
@@ -38,7 +40,7 @@ def test_forward_bf16(name):
     rel_score = float(np.abs(score.cpu().numpy() - g["score"]).max() / np.abs(g["score"]).max())
     d = dict(recon=maxdiff(recon, g["recon"]), mu=maxdiff(mu, g["mu"]), logvar=maxdiff(lv, g["logvar"]), score_rel=rel_score)
     print("bf16", name, json.dumps(d))
-    assert d["recon"] < 2e-2 and d["mu"] < 2e-2 and d["logvar"] < 2e-2 and rel_score < 5e-3, d
+    assert d["recon"] < 2e-3 and d["mu"] < 1e-2 and d["logvar"] < 1e-2 and rel_score < 5e-4, d
 
 
 @pytest.mark.parametrize("name", ["vae_train_mini", "vae_train_1dof", "vae_train_openlab", "vae_train_ns_h128"])
@@ -58,9 +60,9 @@ def test_fused_trainer_bf16(name):
         rep[k] = float(np.linalg.norm(gk - v) / max(np.linalg.norm(v), 1e-12))
     print("bf16", name, "stats", stats.tolist(), "ref", ref.tolist())
     print("bf16", name, "grad rel-L2", json.dumps({k: round(v, 5) for k, v in rep.items()}))
-    assert abs(stats[0] - ref[0]) < 2e-3 * max(1, abs(ref[0]))
-    assert abs(stats[3] - ref[3]) < 2e-2 * max(1, abs(ref[3]))
-    assert max(rep.values()) < 5e-2, rep
+    assert abs(stats[0] - ref[0]) < 5e-4 * max(1, abs(ref[0]))
+    assert abs(stats[3] - ref[3]) < 2e-3 * max(1, abs(ref[3]))
+    assert max(rep.values()) < 2e-2, rep
 
 
 def test_bf16_training_reduces_loss_like_fp32():
@@ -81,8 +83,8 @@ def test_bf16_training_reduces_loss_like_fp32():
             hist.append(float(tr.step(x, 0.05)[0]))
         out[prec] = hist
     print("loss fp32 first/last", out["fp32"][0], out["fp32"][-1], "bf16 first/last", out["bf16"][0], out["bf16"][-1])
-    assert out["fp32"][-1] < 0.8 * out["fp32"][0]
-    assert abs(out["bf16"][-1] - out["fp32"][-1]) < 0.05 * out["fp32"][0]
+    assert out["fp32"][-1] < 0.97 * out["fp32"][0] and out["bf16"][-1] < 0.97 * out["bf16"][0]
+    assert abs(out["bf16"][-1] - out["fp32"][-1]) < 2e-3 * out["fp32"][0]            # measured 1e-6
 
 
 def test_bf16_full_size_properties():
