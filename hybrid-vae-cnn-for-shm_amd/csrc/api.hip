@@ -59,6 +59,8 @@ struct shm_vae_plan {
     size_t h_last, eps, y, xhat, rstd, mu, lv, z, h0, dpre_l2h, dmu, dlv, dyx, dy, dh_last, dh0;
     size_t recon, score, d_recon, d_mu, d_lv, dpre_seq, dx_seq, dpre_tsum, gemm_partial, colsum_scratch;
     size_t gemm_partial_elems;
+    size_t fuse_w;          // per-tile partials of the narrow product folded into the bf16 encoder-L0 backward kernel
+    size_t narrow_scratch;  // block partials of narrow_tn
     size_t params_copy;     // flat fp32 copy of the parameters (head / output layer read them unpacked)
     size_t ws_bytes;
     // call-order state
@@ -240,6 +242,8 @@ extern "C" int shm_vae_plan_create(const shm_vae_config* cfg, int32_t B, int32_t
         upd((int)BT, H, D); upd((int)BT, 4 * H, H); upd((int)BT, 4 * H, D); upd(B, 4 * H, H); upd(B, H, Z); upd(B, Z, H);
         if (bf) { const size_t e = gemm_tn_bf16_partial_elems((int)BT, 4 * H, H); if (e > gp) gp = e; }
         p->gemm_partial_elems = gp;
+        p->fuse_w = take(tiles * 4 * H * (size_t)(D > 4 ? 4 : D));
+        p->narrow_scratch = take(narrow_tn_scratch_elems(4 * H, D));
         p->gemm_partial = take(gp > 0 ? gp : 1);
         size_t cs = colsum_scratch_elems((int)BT, D);
         const size_t cs2 = colsum_scratch_elems(B, 4 * H);
@@ -427,7 +431,7 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
     const void* h_top = at<char>(ws, p->dec[L - 1].h_seq);
     {
         KernelTimer kt("dw_gemm.out", s);
-        if ((rc = gemm(h_top, H, H, d_recon, D, D, BT, grads + p->out_w, 0, 1, 0.f, 0, bf ? 1 : 0, 0))) return rc;
+        if ((rc = launch_narrow_tn(h_top, bf ? 1 : 0, H, H, d_recon, D, BT, grads + p->out_w, 0, at<float>(ws, p->narrow_scratch), s))) return rc;
         if ((rc = launch_colsum(d_recon, D, BT, D, grads + p->out_b, nullptr, cs, s))) return rc;
     }
 
@@ -452,10 +456,14 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
                 a.dpre_seq = at<bf16_t>(ws, p->dpre_seq); a.dpre_tsum = dpre_tsum; a.dx_seq = dx_seq;
                 a.B = B; a.T = T; a.In = st[l].In;
                 a.drop_p = l > 0 ? drop : 0.f; a.drop_seed = p->drop_seed; a.drop_stack = stack;
+                const int ntile = ceil_div(B, 16);
+                const bool fuse_x = !is_dec && l == 0 && D <= 4;
+                if (fuse_x) { a.fuse = 2; a.x = x0; a.Dx = D; a.fuse_w = at<float>(ws, p->fuse_w); }
                 int r;
                 {
                     KernelTimer kt(nm, s);
                     r = launch_lstm_bwd_bf16(H, a, s);
+                    if (!r && fuse_x) r = launch_reduce_partials(a.fuse_w, ntile, (size_t)G * D, grads + st[l].w_ih, nullptr, s);
                 }
                 if (r) return r;
                 KernelTimer kt(gnm, s);
@@ -465,8 +473,8 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
                     if ((r = gemm_bf(dps, G, G, at<char>(ws, st[l - 1].h_seq), H, H, BT, grads + st[l].w_ih, 0, drop, stack))) return r;
                 } else if (st[l].in_const) {
                     if ((r = gemm(dpre_tsum, G, G, hb.h0, H, H, B, grads + st[l].w_ih, 0, 0, 0.f, 0))) return r;
-                } else {
-                    if ((r = gemm(dps, G, G, x0, D, D, BT, grads + st[l].w_ih, 0, 0, 0.f, 0, 1, 0))) return r;
+                } else if (!fuse_x) {
+                    if ((r = launch_narrow_tn(dps, 1, G, G, x0, D, BT, grads + st[l].w_ih, 1, at<float>(ws, p->narrow_scratch), s))) return r;
                 }
                 if ((r = launch_colsum(dpre_tsum, G, B, G, grads + st[l].b_ih, grads + st[l].b_hh, cs, s))) return r;
                 continue;
@@ -500,7 +508,7 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
             } else if (st[l].in_const) {
                 if ((r = gemm(dpre_tsum, G, G, hb.h0, H, H, B, grads + st[l].w_ih, 0, 0, 0.f, 0))) return r;
             } else {
-                if ((r = gemm(dpre_seq, G, G, x0, D, D, BT, grads + st[l].w_ih, 0, 0, 0.f, 0))) return r;
+                if ((r = launch_narrow_tn(dpre_seq, 0, G, G, x0, D, BT, grads + st[l].w_ih, 1, at<float>(ws, p->narrow_scratch), s))) return r;
             }
             if ((r = launch_colsum(dpre_tsum, G, B, G, grads + st[l].b_ih, grads + st[l].b_hh, cs, s))) return r;
         }
@@ -513,16 +521,9 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
     KernelTimer kt_head("head_bwd+grads", s);
     if ((rc = launch_head_bwd(B, H, Z, c.layer_norm, dpre_tsum, prm + p->dec[0].w_ih, at<float>(ws, p->eps), d_mu, d_logvar,
                               head_params(p, prm), hb, s))) return rc;
-    if ((rc = gemm(hb.dpre_l2h, H, H, hb.z, Z, Z, B, grads + p->l2h_w, 0, 0, 0.f, 0))) return rc;
-    if ((rc = launch_colsum(hb.dpre_l2h, H, B, H, grads + p->l2h_b, nullptr, cs, s))) return rc;
-    if ((rc = gemm(hb.dmu, Z, Z, hb.y, H, H, B, grads + p->mu_w, 0, 0, 0.f, 0))) return rc;
-    if ((rc = launch_colsum(hb.dmu, Z, B, Z, grads + p->mu_b, nullptr, cs, s))) return rc;
-    if ((rc = gemm(hb.dlv, Z, Z, hb.y, H, H, B, grads + p->lv_w, 0, 0, 0.f, 0))) return rc;
-    if ((rc = launch_colsum(hb.dlv, Z, B, Z, grads + p->lv_b, nullptr, cs, s))) return rc;
-    if (c.layer_norm) {
-        if ((rc = launch_colsum(hb.dyx, H, B, H, grads + p->ln_w, nullptr, cs, s))) return rc;
-        if ((rc = launch_colsum(hb.dy, H, B, H, grads + p->ln_b, nullptr, cs, s))) return rc;
-    }
+    if ((rc = launch_head_grads(B, H, Z, c.layer_norm, hb, grads + p->l2h_w, grads + p->l2h_b, grads + p->mu_w, grads + p->mu_b,
+                                grads + p->lv_w, grads + p->lv_b, c.layer_norm ? grads + p->ln_w : nullptr,
+                                c.layer_norm ? grads + p->ln_b : nullptr, s))) return rc;
 
     kt_head.~KernelTimer(); kt_head.idx = -1;
     if ((rc = run_stack_bwd(p->enc, 0, x, false))) return rc;

@@ -59,6 +59,10 @@ int launch_head_bwd(int B, int H, int Z, int layer_norm, const float* dpre_tsum,
                     const float* eps, const float* d_mu, const float* d_lv, const HeadParams& p, const HeadBufs& hb,
                     hipStream_t s);
 
+// all head parameter gradients (fc_latent_to_hidden, fc_mu, fc_logvar, LayerNorm) in one launch
+int launch_head_grads(int B, int H, int Z, int layer_norm, const HeadBufs& hb, float* l2h_w, float* l2h_b, float* mu_w, float* mu_b,
+                      float* lv_w, float* lv_b, float* ln_w, float* ln_b, hipStream_t s);
+
 // ---- output layer + per-window score; loss --------------------------------------------------------------
 int launch_out_fwd(int B, int T, int D, int H, const void* h_seq, int h_bf16, const float* Wout, const float* bout,
                    const float* x, float* recon, float* score, hipStream_t s);
@@ -83,6 +87,10 @@ size_t gemm_tn_partial_elems(int R, int M, int N);
 // out[n] = sum_r A[r*lda + n], written to out0 and (if non-null) out1; scratch: colsum_scratch_elems(R,N) floats
 int launch_colsum(const float* A, int lda, int R, int N, float* out0, float* out1, float* scratch, hipStream_t s);
 size_t colsum_scratch_elems(int R, int N);
+// narrow product out[n][m] = sum_r Bn[r][n] A[r][m] (N <= 16 channels; trans_out writes out[m][n]); A fp32 or bf16
+int launch_narrow_tn(const void* A, int a_bf16, int lda, int M, const float* Bn, int N, int R, float* out, int trans_out,
+                     float* scratch, hipStream_t s);
+size_t narrow_tn_scratch_elems(int M, int N);
 // out[i] (and out1[i]) = sum_p partial[p*n + i], p < nparts (fixed order)
 int launch_reduce_partials(const float* partial, int nparts, size_t n, float* out0, float* out1, hipStream_t s);
 
@@ -116,6 +124,10 @@ struct LstmBwdArgsB {
     float* dx_seq;          // [B,T,In] fp32
     int B, T, In, Dy, need_dx;
     float drop_p; uint64_t drop_seed; uint32_t drop_stack;
+    // fuse = 2: dW_ih partials [tile][4H][Dx] accumulated in-kernel from x [B,T,Dx] (Dx <= 4, layer without dx)
+    int fuse, Dx;
+    const float* x;
+    float* fuse_w;
 };
 int launch_lstm_bwd_bf16(int H, const LstmBwdArgsB& a, hipStream_t s);
 

@@ -3,14 +3,19 @@
 //   * W_hh^T and W_ih^T fragments stay in registers for the whole sequence (64 VGPRs each at H=128);
 //   * dpre_t is rounded to bf16 once and used three times: LDS image (operand of dh_rec / dx), HBM copy for the
 //     deferred weight-gradient GEMM (gemm_tn_bf16.hip);
-//   * gate/cell gradients, dc and dh accumulate in fp32.
+//   * gate/cell gradients, dc and dh accumulate in fp32;
+//   * encoder layer 0 with <= 4 channels folds its NARROW weight gradient into the time loop (FUSE = 2:
+//     dW_ih += dpre_t (x) x_t): 64 per-lane fp32 accumulators (the registers W_ih^T would have used), one 16-lane
+//     shuffle reduction after the loop, per-tile partials summed in fixed order by reduce_partials.  That removes a
+//     full pass over dpre_seq for a 4-column output.  (Folding dW_out into the top decoder layer the same way spills
+//     at H = 128 — 256 VGPRs + scratch — so that product goes through narrow_tn in small_kernels.hip.)
 #include "kernels.hpp"
 
 namespace shm {
 
 namespace {
 
-template <int H, bool DROP>
+template <int H, bool DROP, bool NEEDX, int FUSE>
 __global__ void __launch_bounds__(4 * H) lstm_bwd_bf16_kernel(LstmBwdArgsB a) {
     constexpr int NW = H / 16, NTHR = 64 * NW;
     constexpr int KS = H / 8;                      // k-steps of 32 over K = 4H
@@ -29,20 +34,22 @@ __global__ void __launch_bounds__(4 * H) lstm_bwd_bf16_kernel(LstmBwdArgsB a) {
     if (a.dy)
         for (int e = tid; e < Dy * H; e += NTHR) wo_lds[e] = a.Wout[e];
 
-    bf16x8 whT[KS], wxT[KS];
+    bf16x8 whT[KS], wxT[NEEDX ? KS : 1];
     {
         const bf16x8* p = reinterpret_cast<const bf16x8*>(a.WhT) + (size_t)ht * KS * 64 + lane;
 #pragma unroll
         for (int s = 0; s < KS; ++s) whT[s] = p[s * 64];
-        if (a.need_dx) {
+        if constexpr (NEEDX) {
             const bf16x8* px = reinterpret_cast<const bf16x8*>(a.WxT) + (size_t)ht * KS * 64 + lane;
 #pragma unroll
             for (int s = 0; s < KS; ++s) wxT[s] = px[s * 64];
-        } else {
-#pragma unroll
-            for (int s = 0; s < KS; ++s) wxT[s] = whT[s];
         }
     }
+    // fused narrow products: per-lane accumulators
+    f32x4 fw[FUSE == 2 ? 16 : 1];                        // [g*4 + r] over d
+#pragma unroll
+    for (int i = 0; i < (FUSE == 2 ? 16 : 1); ++i) fw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 aux = {0.f, 0.f, 0.f, 0.f};                    // x_t[0..3] of the step being processed
 
     const bf16_t* svg = a.sv_g + (((size_t)tile * T * NW + ht) * 64 + lane) * 16;
     const float* svc = a.sv_c + (((size_t)tile * T * NW + ht) * 64 + lane) * 4;
@@ -59,6 +66,7 @@ __global__ void __launch_bounds__(4 * H) lstm_bwd_bf16_kernel(LstmBwdArgsB a) {
     };
     auto load_dh_above = [&](int t) -> f32x4 {
         f32x4 d = zero4;
+        if constexpr (FUSE != 0) aux = zero4;
         if (!bvalid) return d;
         const size_t row = (size_t)b * T + t;
         if (a.dh_seq) d = *reinterpret_cast<const f32x4*>(a.dh_seq + row * H + u0);
@@ -67,6 +75,9 @@ __global__ void __launch_bounds__(4 * H) lstm_bwd_bf16_kernel(LstmBwdArgsB a) {
                 const float dyv = a.dy[row * Dy + dd];
                 d += dyv * *reinterpret_cast<const f32x4*>(wo_lds + dd * H + u0);
             }
+        }
+        if constexpr (FUSE == 2) {
+            for (int dd = 0; dd < a.Dx; ++dd) aux[dd & 3] = a.x[row * a.Dx + dd];
         }
         if (a.dh_last && t == T - 1) d += *reinterpret_cast<const f32x4*>(a.dh_last + (size_t)b * H + u0);
         return d;
@@ -106,6 +117,10 @@ __global__ void __launch_bounds__(4 * H) lstm_bwd_bf16_kernel(LstmBwdArgsB a) {
             const bf16x4 pb = cvt_bf16x4(dpre[g]);
             *reinterpret_cast<bf16x4*>(dpl + (g * 16 + j) * RS + u0) = pb;
             tsum[g] += dpre[g];
+            if constexpr (FUSE == 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) fw[g * 4 + r] += dpre[g][r] * aux;      // before the prefetch overwrites aux
+            }
             if (bvalid && a.dpre_seq) *reinterpret_cast<bf16x4*>(a.dpre_seq + ((size_t)b * T + t) * 4 * H + g * H + u0) = pb;
         }
         __syncthreads();
@@ -113,7 +128,7 @@ __global__ void __launch_bounds__(4 * H) lstm_bwd_bf16_kernel(LstmBwdArgsB a) {
 
         const bf16_t* brow = dpl + (q * 16 + j) * RS;
         f32x4 acc_h = zero4, acc_x = zero4;
-        if (a.need_dx) {
+        if constexpr (NEEDX) {
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const bf16x8 bv = *reinterpret_cast<const bf16x8*>(brow + 8 * s);
@@ -128,7 +143,7 @@ __global__ void __launch_bounds__(4 * H) lstm_bwd_bf16_kernel(LstmBwdArgsB a) {
             }
         }
         dh_rec = acc_h;
-        if (a.need_dx && ht < MTx && bvalid) {
+        if (NEEDX && ht < MTx && bvalid) {
             f32x4 dx = acc_x;
             const size_t base = ((size_t)b * T + t) * In + u0;
             if (DROP) {
@@ -143,13 +158,36 @@ __global__ void __launch_bounds__(4 * H) lstm_bwd_bf16_kernel(LstmBwdArgsB a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(a.dpre_tsum + (size_t)b * 4 * H + g * H + u0) = tsum[g];
     }
+    // fused narrow products: sum over the 16 windows of the tile (lanes of one quarter), lane j == 0 writes the partial
+    if constexpr (FUSE != 0) {
+        constexpr int NF = 16;
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) fw[i][e] += __shfl_xor(fw[i][e], off, 64);
+        {
+            if (j == 0) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        for (int dd = 0; dd < a.Dx; ++dd)
+                            a.fuse_w[((size_t)tile * 4 * H + g * H + u0 + r) * a.Dx + dd] = fw[g * 4 + r][dd];   // [tile][4H][D]
+            }
+        }
+    }
 }
 
 template <int H>
 int launch_h(const LstmBwdArgsB& a, hipStream_t s) {
     const int tiles = ceil_div(a.B, 16);
     const size_t lds = sizeof(bf16_t) * 2 * 4 * 16 * lds_row_stride(H) + sizeof(float) * (a.dy ? a.Dy * H : 0);
-    auto kern = (a.drop_p > 0.f && a.need_dx) ? lstm_bwd_bf16_kernel<H, true> : lstm_bwd_bf16_kernel<H, false>;
+    void (*kern)(LstmBwdArgsB) = nullptr;
+    const bool drop = a.drop_p > 0.f && a.need_dx;
+    if (a.need_dx) kern = drop ? lstm_bwd_bf16_kernel<H, true, true, 0> : lstm_bwd_bf16_kernel<H, false, true, 0>;
+    else kern = a.fuse == 2 ? lstm_bwd_bf16_kernel<H, false, false, 2> : lstm_bwd_bf16_kernel<H, false, false, 0>;
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(4 * H), lds, s, a);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
@@ -162,6 +200,8 @@ int launch_lstm_bwd_bf16(int H, const LstmBwdArgsB& a, hipStream_t s) {
     SHM_REQUIRE(a.sv_g && a.sv_c, SHM_ESTATE, "lstm_bwd_bf16: no saved forward state");
     SHM_REQUIRE(!a.need_dx || (a.WxT && a.dx_seq && a.In == H), SHM_EINVAL, "lstm_bwd_bf16: dx needs In == H and operands");
     SHM_REQUIRE(!a.dy || (a.Wout && a.Dy > 0 && a.Dy <= 64), SHM_EINVAL, "lstm_bwd_bf16: bad output-layer gradient");
+    SHM_REQUIRE(a.fuse == 0 || (a.fuse == 2 && a.x && a.Dx >= 1 && a.Dx <= 4 && a.fuse_w && !a.need_dx), SHM_EINVAL,
+                "lstm_bwd_bf16: fused narrow product needs <= 4 channels, no dx and its buffer");
     switch (H) {
         case 32: return launch_h<32>(a, s);
         case 64: return launch_h<64>(a, s);

@@ -85,13 +85,16 @@ __global__ void __launch_bounds__(256) head_fwd_kernel(int B, int H, int Z, int 
 }
 
 // ------------------------------------------------------------------------------------------------ head backward
+// Block = 4 windows.  dh0 = dpre_tsum . W_ih(dec0) is the only real work (4H x H weights, L2-resident): the 4H
+// contraction is split over the 4 waves, every weight element is loaded once per block and feeds all 4 windows.
 __global__ void __launch_bounds__(256) head_bwd_kernel(int B, int H, int Z, int layer_norm, const float* __restrict__ dpre_tsum,
                                                        const float* __restrict__ W_ih_dec0, const float* __restrict__ eps,
                                                        const float* __restrict__ d_mu, const float* __restrict__ d_lv,
                                                        HeadParams p, HeadBufs hb) {
-    __shared__ float ds[4][4 * HMAX];    // dpre_tsum row
-    __shared__ float dl[4][HMAX];        // d(pre-tanh) of fc_latent_to_hidden
-    __shared__ float dmz[4][2 * ZMAX];   // dmu | dlv
+    __shared__ float ds[4][4 * HMAX];        // dpre_tsum rows
+    __shared__ float part[4][4][HMAX];       // [m-quarter][window][k]
+    __shared__ float dl[4][HMAX];            // d(pre-tanh) of fc_latent_to_hidden
+    __shared__ float dmz[4][2 * ZMAX];       // dmu | dlv
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row_raw = blockIdx.x * 4 + w;
     const bool valid = row_raw < B;
@@ -100,10 +103,32 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(int B, int H, int Z, int 
 
     for (int m = lane; m < G; m += 64) ds[w][m] = dpre_tsum[(size_t)row * G + m];
     __syncthreads();
-    // dh0 = dpre_tsum . W_ih(dec layer 0)  (the decoder input is the same h0 at every step, temporal_vae.py:68)
+    {
+        float acc[4][HMAX / 64];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < HMAX / 64; ++i) acc[r][i] = 0.f;
+        const int mq = G / 4;
+        for (int m = w * mq; m < (w + 1) * mq; ++m) {
+            float wv[HMAX / 64];
+#pragma unroll
+            for (int i = 0; i < HMAX / 64; ++i) { const int k = lane + 64 * i; wv[i] = k < H ? W_ih_dec0[(size_t)m * H + k] : 0.f; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = ds[r][m];
+#pragma unroll
+                for (int i = 0; i < HMAX / 64; ++i) acc[r][i] = fmaf(d, wv[i], acc[r][i]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < HMAX / 64; ++i) { const int k = lane + 64 * i; if (k < H) part[w][r][k] = acc[r][i]; }
+    }
+    __syncthreads();
     for (int k = lane; k < H; k += 64) {
-        float acc = 0.f;
-        for (int m = 0; m < G; ++m) acc = fmaf(ds[w][m], W_ih_dec0[(size_t)m * H + k], acc);
+        const float acc = (part[0][w][k] + part[1][w][k]) + (part[2][w][k] + part[3][w][k]);
         const float h0 = hb.h0[(size_t)row * H + k];
         const float dp = acc * (1.0f - h0 * h0);
         dl[w][k] = dp;
@@ -149,6 +174,38 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(int B, int H, int Z, int 
             if (k < H && valid) hb.dh_last[(size_t)row * H + k] = rstd * (dxh[i] - m1 - xh[i] * m2);
         }
     }
+}
+
+// All eight head parameter gradients in ONE launch: every output element is a fixed-order sum over the B windows of
+// a product P[b][i] * Q[b][j] (weights) or of P[b][i] alone (biases, LayerNorm).  Block = 64 outputs x 4 window groups.
+struct HeadGradPtrs { float *l2h_w, *l2h_b, *mu_w, *mu_b, *lv_w, *lv_b, *ln_w, *ln_b; };
+__global__ void __launch_bounds__(256) head_grads_kernel(int B, int H, int Z, int layer_norm, HeadBufs hb, HeadGradPtrs g) {
+    __shared__ float red[4][64];
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    const int HZ = H * Z;
+    const int n_total = 3 * HZ + H + 2 * Z + (layer_norm ? 2 * H : 0);
+    const float *P = nullptr, *Q = nullptr;
+    float* out = nullptr;
+    int i = 0, j = 0, ldp = 0, ldq = 0;
+    if (e < HZ) { i = e / Z; j = e % Z; P = hb.dpre_l2h; ldp = H; Q = hb.z; ldq = Z; out = g.l2h_w + e; }
+    else if (e < 2 * HZ) { const int f = e - HZ; i = f / H; j = f % H; P = hb.dmu; ldp = Z; Q = hb.y; ldq = H; out = g.mu_w + f; }
+    else if (e < 3 * HZ) { const int f = e - 2 * HZ; i = f / H; j = f % H; P = hb.dlv; ldp = Z; Q = hb.y; ldq = H; out = g.lv_w + f; }
+    else if (e < n_total) {
+        int f = e - 3 * HZ;
+        if (f < H) { i = f; P = hb.dpre_l2h; ldp = H; out = g.l2h_b + f; }
+        else if ((f -= H) < Z) { i = f; P = hb.dmu; ldp = Z; out = g.mu_b + f; }
+        else if ((f -= Z) < Z) { i = f; P = hb.dlv; ldp = Z; out = g.lv_b + f; }
+        else if ((f -= Z) < H) { i = f; P = hb.dyx; ldp = H; out = g.ln_w + f; }
+        else { f -= H; i = f; P = hb.dy; ldp = H; out = g.ln_b + f; }
+    }
+    float s = 0.f;
+    if (P) {
+        if (Q) for (int b = grp; b < B; b += 4) s = fmaf(P[(size_t)b * ldp + i], Q[(size_t)b * ldq + j], s);
+        else for (int b = grp; b < B; b += 4) s += P[(size_t)b * ldp + i];
+    }
+    red[grp][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (grp == 0 && out) *out = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------ output layer + score
@@ -259,6 +316,47 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __res
     if (out1) out1[i] = s;
 }
 
+// ------------------------------------------------------------------------------------------------ narrow TN product
+// out[n][m] = sum_r Bn[r][n] * A[r][m]  with n < N <= 16 (channel count): dW_out = d_recon^T h_top, dW_ih(enc0) = dpre^T x.
+// A is streamed once (HBM-bound, 2 columns per thread); Bn is a broadcast load.  Block partials -> reduce_partials.
+constexpr int NARROW_BLOCKS = 256;
+template <typename TA, int NMAX>
+__global__ void __launch_bounds__(256) narrow_tn_kernel(const TA* __restrict__ A, int lda, int M, const float* __restrict__ Bn, int N,
+                                                        int R, float* __restrict__ partial) {
+    extern __shared__ float nred[];                     // [groups][NMAX][M]
+    const int tpr = M / 2;                              // threads per row
+    const int groups = 256 / tpr;                       // rows in flight per block (M = 128 -> 4, M = 512 -> 1)
+    const int grp = threadIdx.x / tpr, m = (threadIdx.x - grp * tpr) * 2;
+    const int rows_per_block = (R + gridDim.x - 1) / gridDim.x;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
+    float acc[NMAX][2];
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) acc[n][0] = acc[n][1] = 0.f;
+    if (grp < groups) {
+        for (int r = r0 + grp; r < r1; r += groups) {
+            const float a0 = (float)A[(size_t)r * lda + m], a1 = (float)A[(size_t)r * lda + m + 1];
+#pragma unroll
+            for (int n = 0; n < NMAX; ++n) {
+                if (n < N) { const float bv = Bn[(size_t)r * N + n]; acc[n][0] = fmaf(bv, a0, acc[n][0]); acc[n][1] = fmaf(bv, a1, acc[n][1]); }
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NMAX; ++n) { nred[(grp * NMAX + n) * M + m] = acc[n][0]; nred[(grp * NMAX + n) * M + m + 1] = acc[n][1]; }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < N * M; e += 256) {
+        const int n = e / M, mm = e - n * M;
+        float sum = 0.f;
+        for (int g2 = 0; g2 < groups; ++g2) sum += nred[(g2 * NMAX + n) * M + mm];
+        partial[(size_t)blockIdx.x * N * M + e] = sum;
+    }
+}
+// out2[m][n] = in[n][m]
+__global__ void __launch_bounds__(256) transpose_small_kernel(const float* __restrict__ in, int N, int M, float* __restrict__ out) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < N * M) { const int n = e / M, m = e - n * M; out[(size_t)m * N + n] = in[e]; }
+}
+
 // ------------------------------------------------------------------------------------------------ weight packing
 __global__ void __launch_bounds__(256) pack_fwd_f32_kernel(const float* __restrict__ W, int H, int K, float* __restrict__ dst) {
     const int Kp = (K + 15) & ~15, KQ = Kp >> 2, S4 = KQ >> 2;
@@ -327,6 +425,14 @@ int launch_head_bwd(int B, int H, int Z, int layer_norm, const float* dpre_tsum,
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
+int launch_head_grads(int B, int H, int Z, int layer_norm, const HeadBufs& hb, float* l2h_w, float* l2h_b, float* mu_w, float* mu_b,
+                      float* lv_w, float* lv_b, float* ln_w, float* ln_b, hipStream_t s) {
+    HeadGradPtrs g{l2h_w, l2h_b, mu_w, mu_b, lv_w, lv_b, ln_w, ln_b};
+    const int n_total = 3 * H * Z + H + 2 * Z + (layer_norm ? 2 * H : 0);
+    hipLaunchKernelGGL(head_grads_kernel, dim3(ceil_div(n_total, 64)), dim3(256), 0, s, B, H, Z, layer_norm, hb, g);
+    SHM_LAUNCH_CHECK();
+    return SHM_OK;
+}
 int launch_out_fwd(int B, int T, int D, int H, const void* h_seq, int h_bf16, const float* Wout, const float* bout, const float* x,
                    float* recon, float* score, hipStream_t s) {
     SHM_REQUIRE(D <= DMAX && H <= HMAX, SHM_EINVAL, "out: D=%d (<=%d) H=%d unsupported", D, DMAX, H);
@@ -366,6 +472,27 @@ int launch_pack_fwd_f32(const float* W, int H, int K, float* dst, hipStream_t s)
 int launch_pack_bwd_f32(const float* W, int H, int M, float* dst, hipStream_t s) {
     const size_t n = bwd_pack_elems(H, M);
     hipLaunchKernelGGL(pack_bwd_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, H, M, dst);
+    SHM_LAUNCH_CHECK();
+    return SHM_OK;
+}
+size_t narrow_tn_scratch_elems(int M, int N) { return (size_t)(NARROW_BLOCKS + 1) * M * N; }
+int launch_narrow_tn(const void* A, int a_bf16, int lda, int M, const float* Bn, int N, int R, float* out, int trans_out,
+                     float* scratch, hipStream_t s) {
+    SHM_REQUIRE(N >= 1 && N <= 16 && M >= 2 && M <= 512 && (M & 1) == 0 && 256 % (M / 2) == 0, SHM_EINVAL,
+                "narrow_tn: unsupported shape M=%d N=%d", M, N);
+    const int groups = 256 / (M / 2);
+    const int nmax = N <= 4 ? 4 : 16;
+    const size_t lds = sizeof(float) * groups * nmax * M;
+    const int blocks = R < NARROW_BLOCKS * 8 ? ceil_div(R, 8) : NARROW_BLOCKS;
+#define SHM_NARROW(TA, NM) hipLaunchKernelGGL((narrow_tn_kernel<TA, NM>), dim3(blocks), dim3(256), lds, s, (const TA*)A, lda, M, Bn, N, R, scratch)
+    if (a_bf16) { if (nmax == 4) SHM_NARROW(bf16_t, 4); else SHM_NARROW(bf16_t, 16); }
+    else { if (nmax == 4) SHM_NARROW(float, 4); else SHM_NARROW(float, 16); }
+#undef SHM_NARROW
+    SHM_LAUNCH_CHECK();
+    float* red = trans_out ? scratch + (size_t)blocks * M * N : out;
+    int rc = launch_reduce_partials(scratch, blocks, (size_t)N * M, red, nullptr, s);
+    if (rc || !trans_out) return rc;
+    hipLaunchKernelGGL(transpose_small_kernel, dim3(ceil_div(N * M, 256)), dim3(256), 0, s, red, N, M, out);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
