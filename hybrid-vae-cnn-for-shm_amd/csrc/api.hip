@@ -457,7 +457,7 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
                 a.B = B; a.T = T; a.In = st[l].In;
                 a.drop_p = l > 0 ? drop : 0.f; a.drop_seed = p->drop_seed; a.drop_stack = stack;
                 const int ntile = ceil_div(B, 16);
-                const bool fuse_x = !is_dec && l == 0 && D <= 4;
+                const bool fuse_x = false;   // in-kernel dW_ih (FUSE = 2) measured slower than narrow_tn: +0.26 ms vs -0.15 ms
                 if (fuse_x) { a.fuse = 2; a.x = x0; a.Dx = D; a.fuse_w = at<float>(ws, p->fuse_w); }
                 int r;
                 {

@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(4 * H) lstm_bwd_bf16_kernel(LstmBwdArgsB a) {
         const bf16x8 lo = *reinterpret_cast<const bf16x8*>(p), hi = *reinterpret_cast<const bf16x8*>(p + 8);
 #pragma unroll
         for (int r = 0; r < 4; ++r) { s_i[r] = (float)lo[r]; s_f[r] = (float)lo[4 + r]; s_g[r] = (float)hi[r]; s_o[r] = (float)hi[4 + r]; }
-        s_c = *reinterpret_cast<const f32x4*>(svc + (size_t)t * NW * 64 * 4);
+        s_c = s_cp;                                       // c_t was fetched as "c_{t-1}" one iteration ago
         s_cp = t > 0 ? *reinterpret_cast<const f32x4*>(svc + (size_t)(t - 1) * NW * 64 * 4) : zero4;
     };
     auto load_dh_above = [&](int t) -> f32x4 {
@@ -91,6 +91,7 @@ __global__ void __launch_bounds__(4 * H) lstm_bwd_bf16_kernel(LstmBwdArgsB a) {
     f32x4 tsum[4] = {zero4, zero4, zero4, zero4};
 
     __syncthreads();
+    s_cp = *reinterpret_cast<const f32x4*>(svc + (size_t)(T - 1) * NW * 64 * 4);
     load_saved(T - 1);
     f32x4 dha = load_dh_above(T - 1);
 

@@ -319,29 +319,52 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __res
 // ------------------------------------------------------------------------------------------------ narrow TN product
 // out[n][m] = sum_r Bn[r][n] * A[r][m]  with n < N <= 16 (channel count): dW_out = d_recon^T h_top, dW_ih(enc0) = dpre^T x.
 // A is streamed once (HBM-bound, 2 columns per thread); Bn is a broadcast load.  Block partials -> reduce_partials.
-constexpr int NARROW_BLOCKS = 256;
-template <typename TA, int NMAX>
+constexpr int NARROW_BLOCKS = 1024;
+template <typename T, int CPT> struct VecLoad;
+template <> struct VecLoad<float, 2> { static __device__ __forceinline__ void ld(const float* p, float (&v)[2]) { const f32x2 t = *reinterpret_cast<const f32x2*>(p); v[0] = t[0]; v[1] = t[1]; } };
+template <> struct VecLoad<float, 8> { static __device__ __forceinline__ void ld(const float* p, float (&v)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; } } };
+template <> struct VecLoad<bf16_t, 2> { static __device__ __forceinline__ void ld(const bf16_t* p, float (&v)[2]) { const bf16x2 t = *reinterpret_cast<const bf16x2*>(p); v[0] = (float)t[0]; v[1] = (float)t[1]; } };
+template <> struct VecLoad<bf16_t, 8> { static __device__ __forceinline__ void ld(const bf16_t* p, float (&v)[8]) {
+    const bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)t[i]; } };
+
+// CPT columns per thread: 8 (one 16/32-byte vector load per row) for <= 4 channels, 2 for up to 16 channels.
+template <typename TA, int NMAX, int CPT>
 __global__ void __launch_bounds__(256) narrow_tn_kernel(const TA* __restrict__ A, int lda, int M, const float* __restrict__ Bn, int N,
                                                         int R, float* __restrict__ partial) {
     extern __shared__ float nred[];                     // [groups][NMAX][M]
-    const int tpr = M / 2;                              // threads per row
-    const int groups = 256 / tpr;                       // rows in flight per block (M = 128 -> 4, M = 512 -> 1)
-    const int grp = threadIdx.x / tpr, m = (threadIdx.x - grp * tpr) * 2;
+    const int tpr = M / CPT;                            // threads per row
+    const int groups = 256 / tpr;                       // rows in flight per block
+    const int grp = threadIdx.x / tpr, m = (threadIdx.x - grp * tpr) * CPT;
     const int rows_per_block = (R + gridDim.x - 1) / gridDim.x;
     const int r0 = blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
-    float acc[NMAX][2];
+    float acc[NMAX][CPT];
 #pragma unroll
-    for (int n = 0; n < NMAX; ++n) acc[n][0] = acc[n][1] = 0.f;
+    for (int n = 0; n < NMAX; ++n)
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) acc[n][c] = 0.f;
     if (grp < groups) {
+#pragma unroll 2
         for (int r = r0 + grp; r < r1; r += groups) {
-            const float a0 = (float)A[(size_t)r * lda + m], a1 = (float)A[(size_t)r * lda + m + 1];
+            float av[CPT];
+            VecLoad<TA, CPT>::ld(A + (size_t)r * lda + m, av);
 #pragma unroll
             for (int n = 0; n < NMAX; ++n) {
-                if (n < N) { const float bv = Bn[(size_t)r * N + n]; acc[n][0] = fmaf(bv, a0, acc[n][0]); acc[n][1] = fmaf(bv, a1, acc[n][1]); }
+                if (n < N) {
+                    const float bv = Bn[(size_t)r * N + n];
+#pragma unroll
+                    for (int c = 0; c < CPT; ++c) acc[n][c] = fmaf(bv, av[c], acc[n][c]);
+                }
             }
         }
 #pragma unroll
-        for (int n = 0; n < NMAX; ++n) { nred[(grp * NMAX + n) * M + m] = acc[n][0]; nred[(grp * NMAX + n) * M + m + 1] = acc[n][1]; }
+        for (int n = 0; n < NMAX; ++n)
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) nred[(grp * NMAX + n) * M + m + c] = acc[n][c];
     }
     __syncthreads();
     for (int e = threadIdx.x; e < N * M; e += 256) {
@@ -478,15 +501,15 @@ int launch_pack_bwd_f32(const float* W, int H, int M, float* dst, hipStream_t s)
 size_t narrow_tn_scratch_elems(int M, int N) { return (size_t)(NARROW_BLOCKS + 1) * M * N; }
 int launch_narrow_tn(const void* A, int a_bf16, int lda, int M, const float* Bn, int N, int R, float* out, int trans_out,
                      float* scratch, hipStream_t s) {
-    SHM_REQUIRE(N >= 1 && N <= 16 && M >= 2 && M <= 512 && (M & 1) == 0 && 256 % (M / 2) == 0, SHM_EINVAL,
-                "narrow_tn: unsupported shape M=%d N=%d", M, N);
-    const int groups = 256 / (M / 2);
-    const int nmax = N <= 4 ? 4 : 16;
+    const int cpt = N <= 4 ? 8 : 2, nmax = N <= 4 ? 4 : 16;
+    SHM_REQUIRE(N >= 1 && N <= 16 && M >= cpt && M <= 512 && M % cpt == 0 && 256 % (M / cpt) == 0 && lda % cpt == 0, SHM_EINVAL,
+                "narrow_tn: unsupported shape M=%d N=%d lda=%d", M, N, lda);
+    const int groups = 256 / (M / cpt);
     const size_t lds = sizeof(float) * groups * nmax * M;
-    const int blocks = R < NARROW_BLOCKS * 8 ? ceil_div(R, 8) : NARROW_BLOCKS;
-#define SHM_NARROW(TA, NM) hipLaunchKernelGGL((narrow_tn_kernel<TA, NM>), dim3(blocks), dim3(256), lds, s, (const TA*)A, lda, M, Bn, N, R, scratch)
-    if (a_bf16) { if (nmax == 4) SHM_NARROW(bf16_t, 4); else SHM_NARROW(bf16_t, 16); }
-    else { if (nmax == 4) SHM_NARROW(float, 4); else SHM_NARROW(float, 16); }
+    const int blocks = R < NARROW_BLOCKS * groups * 2 ? ceil_div(R, groups * 2) : NARROW_BLOCKS;
+#define SHM_NARROW(TA, NM, CP) hipLaunchKernelGGL((narrow_tn_kernel<TA, NM, CP>), dim3(blocks), dim3(256), lds, s, (const TA*)A, lda, M, Bn, N, R, scratch)
+    if (a_bf16) { if (nmax == 4) SHM_NARROW(bf16_t, 4, 8); else SHM_NARROW(bf16_t, 16, 2); }
+    else { if (nmax == 4) SHM_NARROW(float, 4, 8); else SHM_NARROW(float, 16, 2); }
 #undef SHM_NARROW
     SHM_LAUNCH_CHECK();
     float* red = trans_out ? scratch + (size_t)blocks * M * N : out;
