@@ -431,8 +431,8 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
     const void* h_top = at<char>(ws, p->dec[L - 1].h_seq);
     {
         KernelTimer kt("dw_gemm.out", s);
-        if ((rc = launch_narrow_tn(h_top, bf ? 1 : 0, H, H, d_recon, D, BT, grads + p->out_w, 0, at<float>(ws, p->narrow_scratch), s))) return rc;
-        if ((rc = launch_colsum(d_recon, D, BT, D, grads + p->out_b, nullptr, cs, s))) return rc;
+        if ((rc = launch_narrow_tn(h_top, bf ? 1 : 0, H, H, d_recon, D, BT, grads + p->out_w, 0, grads + p->out_b,
+                                   at<float>(ws, p->narrow_scratch), s))) return rc;
     }
 
     auto run_stack_bwd = [&](LayerInst* st, uint32_t stack, const float* x0, bool is_dec) -> int {
@@ -474,7 +474,7 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
                 } else if (st[l].in_const) {
                     if ((r = gemm(dpre_tsum, G, G, hb.h0, H, H, B, grads + st[l].w_ih, 0, 0, 0.f, 0))) return r;
                 } else if (!fuse_x) {
-                    if ((r = launch_narrow_tn(dps, 1, G, G, x0, D, BT, grads + st[l].w_ih, 1, at<float>(ws, p->narrow_scratch), s))) return r;
+                    if ((r = launch_narrow_tn(dps, 1, G, G, x0, D, BT, grads + st[l].w_ih, 1, nullptr, at<float>(ws, p->narrow_scratch), s))) return r;
                 }
                 if ((r = launch_colsum(dpre_tsum, G, B, G, grads + st[l].b_ih, grads + st[l].b_hh, cs, s))) return r;
                 continue;
@@ -508,7 +508,7 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
             } else if (st[l].in_const) {
                 if ((r = gemm(dpre_tsum, G, G, hb.h0, H, H, B, grads + st[l].w_ih, 0, 0, 0.f, 0))) return r;
             } else {
-                if ((r = launch_narrow_tn(dpre_seq, 0, G, G, x0, D, BT, grads + st[l].w_ih, 1, at<float>(ws, p->narrow_scratch), s))) return r;
+                if ((r = launch_narrow_tn(dpre_seq, 0, G, G, x0, D, BT, grads + st[l].w_ih, 1, nullptr, at<float>(ws, p->narrow_scratch), s))) return r;
             }
             if ((r = launch_colsum(dpre_tsum, G, B, G, grads + st[l].b_ih, grads + st[l].b_hh, cs, s))) return r;
         }

@@ -88,8 +88,9 @@ size_t gemm_tn_partial_elems(int R, int M, int N);
 int launch_colsum(const float* A, int lda, int R, int N, float* out0, float* out1, float* scratch, hipStream_t s);
 size_t colsum_scratch_elems(int R, int N);
 // narrow product out[n][m] = sum_r Bn[r][n] A[r][m] (N <= 16 channels; trans_out writes out[m][n]); A fp32 or bf16
+// bsum_out (optional, natural layout only): [N] column sums of Bn (the bias gradient that goes with the product)
 int launch_narrow_tn(const void* A, int a_bf16, int lda, int M, const float* Bn, int N, int R, float* out, int trans_out,
-                     float* scratch, hipStream_t s);
+                     float* bsum_out, float* scratch, hipStream_t s);
 size_t narrow_tn_scratch_elems(int M, int N);
 // out[i] (and out1[i]) = sum_p partial[p*n + i], p < nparts (fixed order)
 int launch_reduce_partials(const float* partial, int nparts, size_t n, float* out0, float* out1, hipStream_t s);

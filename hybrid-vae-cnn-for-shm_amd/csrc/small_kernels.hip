@@ -306,20 +306,37 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ A
     if (g == 0 && c < N)
         out[(size_t)blockIdx.y * N + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
+// block = 32 outputs x 8 partial-groups: group g sums partials g, g+8, ... (4 independent chains), then a fixed-order
+// combine over the groups — deterministic, and latency-tolerant even for few outputs and many partials.
 __global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __restrict__ partial, int nparts, size_t n,
                                                               float* __restrict__ out0, float* __restrict__ out1) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * n + i];
-    out0[i] = s;
-    if (out1) out1[i] = s;
+    __shared__ float red[8][32];
+    const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const size_t i = (size_t)blockIdx.x * 32 + o;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < n) {
+        int p = grp;
+        for (; p + 24 < nparts; p += 32) {
+            s0 += partial[(size_t)p * n + i];
+            s1 += partial[(size_t)(p + 8) * n + i];
+            s2 += partial[(size_t)(p + 16) * n + i];
+            s3 += partial[(size_t)(p + 24) * n + i];
+        }
+        for (; p < nparts; p += 8) s0 += partial[(size_t)p * n + i];
+    }
+    red[grp][o] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (grp == 0 && i < n) {
+        const float v = ((red[0][o] + red[1][o]) + (red[2][o] + red[3][o])) + ((red[4][o] + red[5][o]) + (red[6][o] + red[7][o]));
+        out0[i] = v;
+        if (out1) out1[i] = v;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ narrow TN product
 // out[n][m] = sum_r Bn[r][n] * A[r][m]  with n < N <= 16 (channel count): dW_out = d_recon^T h_top, dW_ih(enc0) = dpre^T x.
 // A is streamed once (HBM-bound, 2 columns per thread); Bn is a broadcast load.  Block partials -> reduce_partials.
-constexpr int NARROW_BLOCKS = 1024;
+constexpr int NARROW_BLOCKS = 512;
 template <typename T, int CPT> struct VecLoad;
 template <> struct VecLoad<float, 2> { static __device__ __forceinline__ void ld(const float* p, float (&v)[2]) { const f32x2 t = *reinterpret_cast<const f32x2*>(p); v[0] = t[0]; v[1] = t[1]; } };
 template <> struct VecLoad<float, 8> { static __device__ __forceinline__ void ld(const float* p, float (&v)[8]) {
@@ -335,18 +352,21 @@ template <> struct VecLoad<bf16_t, 8> { static __device__ __forceinline__ void l
 // CPT columns per thread: 8 (one 16/32-byte vector load per row) for <= 4 channels, 2 for up to 16 channels.
 template <typename TA, int NMAX, int CPT>
 __global__ void __launch_bounds__(256) narrow_tn_kernel(const TA* __restrict__ A, int lda, int M, const float* __restrict__ Bn, int N,
-                                                        int R, float* __restrict__ partial) {
-    extern __shared__ float nred[];                     // [groups][NMAX][M]
+                                                        int R, float* __restrict__ partial, int with_bsum) {
+    extern __shared__ float nred[];                     // [groups][NMAX][M] (+ [groups][NMAX] column sums of Bn)
     const int tpr = M / CPT;                            // threads per row
     const int groups = 256 / tpr;                       // rows in flight per block
     const int grp = threadIdx.x / tpr, m = (threadIdx.x - grp * tpr) * CPT;
     const int rows_per_block = (R + gridDim.x - 1) / gridDim.x;
     const int r0 = blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
-    float acc[NMAX][CPT];
+    float acc[NMAX][CPT], bs[NMAX];
 #pragma unroll
-    for (int n = 0; n < NMAX; ++n)
+    for (int n = 0; n < NMAX; ++n) {
+        bs[n] = 0.f;
 #pragma unroll
         for (int c = 0; c < CPT; ++c) acc[n][c] = 0.f;
+    }
+    const int stride = N * M + (with_bsum ? N : 0);      // floats per block partial
     if (grp < groups) {
 #pragma unroll 2
         for (int r = r0 + grp; r < r1; r += groups) {
@@ -356,6 +376,7 @@ __global__ void __launch_bounds__(256) narrow_tn_kernel(const TA* __restrict__ A
             for (int n = 0; n < NMAX; ++n) {
                 if (n < N) {
                     const float bv = Bn[(size_t)r * N + n];
+                    bs[n] += bv;
 #pragma unroll
                     for (int c = 0; c < CPT; ++c) acc[n][c] = fmaf(bv, av[c], acc[n][c]);
                 }
@@ -365,13 +386,22 @@ __global__ void __launch_bounds__(256) narrow_tn_kernel(const TA* __restrict__ A
         for (int n = 0; n < NMAX; ++n)
 #pragma unroll
             for (int c = 0; c < CPT; ++c) nred[(grp * NMAX + n) * M + m + c] = acc[n][c];
+        if (m == 0) {
+#pragma unroll
+            for (int n = 0; n < NMAX; ++n) nred[groups * NMAX * M + grp * NMAX + n] = bs[n];
+        }
     }
     __syncthreads();
     for (int e = threadIdx.x; e < N * M; e += 256) {
         const int n = e / M, mm = e - n * M;
         float sum = 0.f;
         for (int g2 = 0; g2 < groups; ++g2) sum += nred[(g2 * NMAX + n) * M + mm];
-        partial[(size_t)blockIdx.x * N * M + e] = sum;
+        partial[(size_t)blockIdx.x * stride + e] = sum;
+    }
+    if (with_bsum && threadIdx.x < N) {
+        float sum = 0.f;
+        for (int g2 = 0; g2 < groups; ++g2) sum += nred[groups * NMAX * M + g2 * NMAX + threadIdx.x];
+        partial[(size_t)blockIdx.x * stride + N * M + threadIdx.x] = sum;
     }
 }
 // out2[m][n] = in[n][m]
@@ -476,7 +506,7 @@ int launch_vae_loss(int B, int T, int D, int Z, const float* x, const float* rec
 }
 size_t colsum_scratch_elems(int R, int N) { return (size_t)ceil_div(R, CS_ROWS) * N; }
 int launch_reduce_partials(const float* partial, int nparts, size_t n, float* out0, float* out1, hipStream_t s) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, partial, nparts, n, out0, out1);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, partial, nparts, n, out0, out1);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
@@ -498,25 +528,33 @@ int launch_pack_bwd_f32(const float* W, int H, int M, float* dst, hipStream_t s)
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
-size_t narrow_tn_scratch_elems(int M, int N) { return (size_t)(NARROW_BLOCKS + 1) * M * N; }
+size_t narrow_tn_scratch_elems(int M, int N) { return (size_t)(NARROW_BLOCKS + 1) * (M * N + N); }
 int launch_narrow_tn(const void* A, int a_bf16, int lda, int M, const float* Bn, int N, int R, float* out, int trans_out,
-                     float* scratch, hipStream_t s) {
+                     float* bsum_out, float* scratch, hipStream_t s) {
     const int cpt = N <= 4 ? 8 : 2, nmax = N <= 4 ? 4 : 16;
     SHM_REQUIRE(N >= 1 && N <= 16 && M >= cpt && M <= 512 && M % cpt == 0 && 256 % (M / cpt) == 0 && lda % cpt == 0, SHM_EINVAL,
                 "narrow_tn: unsupported shape M=%d N=%d lda=%d", M, N, lda);
+    SHM_REQUIRE(!(bsum_out && trans_out), SHM_EINVAL, "narrow_tn: column sums only with the natural output layout");
     const int groups = 256 / (M / cpt);
-    const size_t lds = sizeof(float) * groups * nmax * M;
+    const size_t lds = sizeof(float) * (groups * nmax * M + groups * nmax);
     const int blocks = R < NARROW_BLOCKS * groups * 2 ? ceil_div(R, groups * 2) : NARROW_BLOCKS;
-#define SHM_NARROW(TA, NM, CP) hipLaunchKernelGGL((narrow_tn_kernel<TA, NM, CP>), dim3(blocks), dim3(256), lds, s, (const TA*)A, lda, M, Bn, N, R, scratch)
+    const int wb = bsum_out ? 1 : 0;
+    const size_t stride = (size_t)M * N + (wb ? N : 0);
+#define SHM_NARROW(TA, NM, CP) hipLaunchKernelGGL((narrow_tn_kernel<TA, NM, CP>), dim3(blocks), dim3(256), lds, s, (const TA*)A, lda, M, Bn, N, R, scratch, wb)
     if (a_bf16) { if (nmax == 4) SHM_NARROW(bf16_t, 4, 8); else SHM_NARROW(bf16_t, 16, 2); }
     else { if (nmax == 4) SHM_NARROW(float, 4, 8); else SHM_NARROW(float, 16, 2); }
 #undef SHM_NARROW
     SHM_LAUNCH_CHECK();
-    float* red = trans_out ? scratch + (size_t)blocks * M * N : out;
-    int rc = launch_reduce_partials(scratch, blocks, (size_t)N * M, red, nullptr, s);
-    if (rc || !trans_out) return rc;
-    hipLaunchKernelGGL(transpose_small_kernel, dim3(ceil_div(N * M, 256)), dim3(256), 0, s, red, N, M, out);
-    SHM_LAUNCH_CHECK();
+    float* red = scratch + (size_t)blocks * stride;          // [N*M (+N)] reduced
+    int rc = launch_reduce_partials(scratch, blocks, stride, red, nullptr, s);
+    if (rc) return rc;
+    if (trans_out) {
+        hipLaunchKernelGGL(transpose_small_kernel, dim3(ceil_div(N * M, 256)), dim3(256), 0, s, red, N, M, out);
+        SHM_LAUNCH_CHECK();
+    } else {
+        SHM_HIP_CHECK(hipMemcpyAsync(out, red, sizeof(float) * M * N, hipMemcpyDeviceToDevice, s));
+        if (wb) SHM_HIP_CHECK(hipMemcpyAsync(bsum_out, red + (size_t)M * N, sizeof(float) * N, hipMemcpyDeviceToDevice, s));
+    }
     return SHM_OK;
 }
 int launch_pack_fwd_bf16(const float* W, int H, int K, bf16_t* dst, hipStream_t s) {
