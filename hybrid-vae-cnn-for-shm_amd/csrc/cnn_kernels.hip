@@ -1,0 +1,475 @@
+// cnn_kernels.hip — the CNN fault classifier (reference 4DOF/Scripts/Models/cnn_model.py:14-51) as gfx950 kernels, fp32.
+//
+//   conv3x3 (pad 1, im2col-free: the whole [C,T,D] window sits in LDS, one thread per output pixel, all output
+//   channels in registers) -> BatchNorm2d (batch statistics in train mode, running statistics in eval) -> ReLU ->
+//   MaxPool2d(2) with the first-maximum rule, twice; flatten (C,H,W); Linear+ReLU+Dropout; Linear; CrossEntropy.
+// Backward mirrors it: pool/ReLU/BatchNorm backward in two passes (per-channel sums, then apply), conv data gradient
+// (conv2 only) and weight gradients with per-window partials reduced in a fixed order (bitwise reproducible).
+// The windows are tiny (T*D <= 1200 pixels) and the step is launch/latency-bound, so the kernels favour simple,
+// fully-coalesced NCHW accesses over MFMA; one workgroup per window throughout.
+#include "cnn_kernels.hpp"
+
+namespace shm {
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+// sum over the 256 threads of a block; red: >= 4 floats of LDS; all threads get the result
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ------------------------------------------------------------------------------------------------ conv forward
+// grid = B, block = 256.  LDS: x[CIN][H*W] | w[(ci*9+k)][COUT] | red[4]
+template <int CIN, int COUT, bool STATS>
+__global__ void __launch_bounds__(256) conv3x3_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ y,
+                                                          float* __restrict__ part, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int HW = H * W, b = blockIdx.x, tid = threadIdx.x;
+    float* xs = sm;
+    float* ws = sm + ((CIN * HW + 3) & ~3);          // keep the weight rows 16-byte aligned for the float4 reads
+    float* red = ws + CIN * 9 * COUT;
+    for (int e = tid; e < CIN * HW; e += 256) xs[e] = x[(size_t)b * CIN * HW + e];
+    for (int e = tid; e < COUT * CIN * 9; e += 256) {           // w[co][ci][k] -> ws[(ci*9+k)*COUT + co]
+        const int co = e / (CIN * 9), r = e - co * CIN * 9;
+        ws[r * COUT + co] = w[e];
+    }
+    __syncthreads();
+    float s1[COUT], s2[COUT];
+    if (STATS) {
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) s1[co] = s2[co] = 0.f;
+    }
+    for (int p = tid; p < HW; p += 256) {
+        const int h = p / W, ww = p - h * W;
+        float acc[COUT];
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[co] = bias[co];
+        for (int ci = 0; ci < CIN; ++ci) {
+            float v[9];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int hh = h + kh - 1, w2 = ww + kw - 1;
+                    v[kh * 3 + kw] = (hh >= 0 && hh < H && w2 >= 0 && w2 < W) ? xs[ci * HW + hh * W + w2] : 0.f;
+                }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const float* wr = ws + (ci * 9 + k) * COUT;
+#pragma unroll
+                for (int co = 0; co < COUT; co += 4) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + co);
+                    acc[co] = fmaf(v[k], w4[0], acc[co]); acc[co + 1] = fmaf(v[k], w4[1], acc[co + 1]);
+                    acc[co + 2] = fmaf(v[k], w4[2], acc[co + 2]); acc[co + 3] = fmaf(v[k], w4[3], acc[co + 3]);
+                }
+            }
+        }
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            y[((size_t)b * COUT + co) * HW + p] = acc[co];
+            if (STATS) { s1[co] += acc[co]; s2[co] = fmaf(acc[co], acc[co], s2[co]); }
+        }
+    }
+    if (STATS) {
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            const float a = block_sum(s1[co], red);
+            const float q = block_sum(s2[co], red);
+            if (tid == 0) { part[((size_t)b * COUT + co) * 2] = a; part[((size_t)b * COUT + co) * 2 + 1] = q; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ BatchNorm statistics
+// one block; thread c < C.  train: batch mean / biased var from the per-window partials (fp64 accumulation), running
+// statistics updated with momentum 0.1 and the unbiased variance; eval: running statistics.
+__global__ void __launch_bounds__(64) bn_finalize_kernel(int C, int B, long long n_per_channel, int train, const float* __restrict__ part,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                         float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                         float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    float mean, var;
+    if (train) {
+        double s = 0.0, q = 0.0;
+        for (int b = 0; b < B; ++b) { s += (double)part[((size_t)b * C + c) * 2]; q += (double)part[((size_t)b * C + c) * 2 + 1]; }
+        const double m = s / (double)n_per_channel;
+        double v = q / (double)n_per_channel - m * m;
+        if (v < 0.0) v = 0.0;
+        mean = (float)m; var = (float)v;
+        const double unb = n_per_channel > 1 ? v * (double)n_per_channel / (double)(n_per_channel - 1) : v;
+        run_mean[c] = 0.9f * run_mean[c] + 0.1f * mean;
+        run_var[c] = 0.9f * run_var[c] + 0.1f * (float)unb;
+    } else {
+        mean = run_mean[c]; var = run_var[c];
+    }
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    mean_out[c] = mean; rstd_out[c] = rstd;
+    scale[c] = gamma[c] * rstd;
+    shift[c] = beta[c] - mean * gamma[c] * rstd;
+}
+
+// ------------------------------------------------------------------------------------------------ BN + ReLU + MaxPool2
+// grid = B.  idx: 0..3 = position (kh*2+kw) of the first maximum of the ReLU'd 2x2 cell, 4 = cell is dead (max <= 0)
+__global__ void __launch_bounds__(256) bn_relu_pool_kernel(int C, int H, int W, const float* __restrict__ y,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           float* __restrict__ out, unsigned char* __restrict__ idx) {
+    const int Hp = H / 2, Wp = W / 2, b = blockIdx.x;
+    const int n = C * Hp * Wp;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const int c = e / (Hp * Wp), r = e - c * Hp * Wp, hp = r / Wp, wp = r - hp * Wp;
+        const float* yp = y + ((size_t)b * C + c) * H * W + (size_t)(2 * hp) * W + 2 * wp;
+        const float sc = scale[c], sh = shift[c];
+        float best = fmaxf(fmaf(yp[0], sc, sh), 0.f);
+        int bi = 0;
+        const float v1 = fmaxf(fmaf(yp[1], sc, sh), 0.f), v2 = fmaxf(fmaf(yp[W], sc, sh), 0.f), v3 = fmaxf(fmaf(yp[W + 1], sc, sh), 0.f);
+        if (v1 > best) { best = v1; bi = 1; }
+        if (v2 > best) { best = v2; bi = 2; }
+        if (v3 > best) { best = v3; bi = 3; }
+        out[(size_t)b * n + e] = best;
+        if (idx) idx[(size_t)b * n + e] = best > 0.f ? (unsigned char)bi : (unsigned char)4;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ dense layers
+// out[b][o] = sum_f in[b][f] W[o][f] + bias[o]; optional ReLU (+ pre-activation copy) and dropout.  32x32 tiles.
+__global__ void __launch_bounds__(256) linear_fwd_kernel(int B, int F, int O, const float* __restrict__ in, const float* __restrict__ Wt,
+                                                         const float* __restrict__ bias, float* __restrict__ pre, float* __restrict__ out,
+                                                         int relu, float drop_p, unsigned long long drop_seed) {
+    __shared__ float sI[32][33];
+    __shared__ float sW[32][33];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int b0 = blockIdx.y * 32, o0 = blockIdx.x * 32;
+    float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    for (int f0 = 0; f0 < F; f0 += 32) {
+        for (int e = threadIdx.x; e < 1024; e += 256) {
+            const int r = e >> 5, k = e & 31;
+            sI[r][k] = (b0 + r < B && f0 + k < F) ? in[(size_t)(b0 + r) * F + f0 + k] : 0.f;
+            sW[r][k] = (o0 + r < O && f0 + k < F) ? Wt[(size_t)(o0 + r) * F + f0 + k] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) {
+            const float i0 = sI[ty][k], i1 = sI[ty + 16][k], w0 = sW[tx][k], w1 = sW[tx + 16][k];
+            acc[0][0] = fmaf(i0, w0, acc[0][0]); acc[0][1] = fmaf(i0, w1, acc[0][1]);
+            acc[1][0] = fmaf(i1, w0, acc[1][0]); acc[1][1] = fmaf(i1, w1, acc[1][1]);
+        }
+        __syncthreads();
+    }
+    const uint32_t thr = drop_threshold(drop_p);
+    const float dscale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {
+            const int b = b0 + ty + 16 * i, o = o0 + tx + 16 * jn;
+            if (b < B && o < O) {
+                float v = acc[i][jn] + bias[o];
+                if (pre) pre[(size_t)b * O + o] = v;
+                if (relu) v = fmaxf(v, 0.f);
+                if (drop_p > 0.f) v = drop_hash(drop_seed, 2u, (uint32_t)(b * O + o)) >= thr ? v * dscale : 0.f;
+                out[(size_t)b * O + o] = v;
+            }
+        }
+}
+
+// dx[b][f] = sum_o dy[b][o] W[o][f]; optional ReLU mask (pre > 0) and dropout mask on the result (fc2 -> fc1 hand-off)
+__global__ void __launch_bounds__(256) linear_bwd_dx_kernel(int B, int F, int O, const float* __restrict__ dy, const float* __restrict__ Wt,
+                                                            const float* __restrict__ pre, float* __restrict__ dx, float drop_p,
+                                                            unsigned long long drop_seed) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)B * F) return;
+    const int b = (int)(i / F), f = (int)(i - (size_t)b * F);
+    float acc = 0.f;
+    for (int o = 0; o < O; ++o) acc = fmaf(dy[(size_t)b * O + o], Wt[(size_t)o * F + f], acc);
+    if (drop_p > 0.f) acc = drop_hash(drop_seed, 2u, (uint32_t)i) >= drop_threshold(drop_p) ? acc / (1.0f - drop_p) : 0.f;
+    if (pre) acc = pre[i] > 0.f ? acc : 0.f;
+    dx[i] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------ cross-entropy
+// one block: loss = mean_b -log softmax(logits)[y_b]; dlogits = (softmax - onehot) / B    (nn.CrossEntropyLoss())
+__global__ void __launch_bounds__(256) ce_loss_kernel(int B, int NC, const float* __restrict__ logits, const long long* __restrict__ labels,
+                                                      float* __restrict__ dlogits, float* __restrict__ loss) {
+    __shared__ float red[4];
+    float ls = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const float* l = logits + (size_t)b * NC;
+        float mx = l[0];
+        for (int c = 1; c < NC; ++c) mx = fmaxf(mx, l[c]);
+        float se = 0.f;
+        for (int c = 0; c < NC; ++c) se += expf(l[c] - mx);
+        const float lse = mx + logf(se);
+        const int yb = (int)labels[b];
+        ls += lse - l[yb];
+        for (int c = 0; c < NC; ++c) dlogits[(size_t)b * NC + c] = (expf(l[c] - lse) - (c == yb ? 1.f : 0.f)) / (float)B;
+    }
+    const float tot = block_sum(ls, red);
+    if (threadIdx.x == 0) *loss = tot / (float)B;
+}
+
+// class = argmax, p1 = softmax[:, 1]   (06_test_full_pipeline.py:367-371)
+__global__ void __launch_bounds__(256) softmax_argmax_kernel(int B, int NC, const float* __restrict__ logits, long long* __restrict__ cls,
+                                                             float* __restrict__ p1) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const float* l = logits + (size_t)b * NC;
+    float mx = l[0]; int am = 0;
+    for (int c = 1; c < NC; ++c) if (l[c] > mx) { mx = l[c]; am = c; }
+    float se = 0.f;
+    for (int c = 0; c < NC; ++c) se += expf(l[c] - mx);
+    if (cls) cls[b] = am;
+    if (p1) p1[b] = NC > 1 ? expf(l[1] - mx) / se : 1.f;
+}
+
+// xin = stack([z, (z - zhat)^2], dim=1)   (05_train_cnn.py:137-138)
+__global__ void __launch_bounds__(256) build_input_kernel(int B, int TD, const float* __restrict__ z, const float* __restrict__ zhat,
+                                                          float* __restrict__ xin) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)B * TD) return;
+    const size_t b = i / TD, r = i - b * TD;
+    const float a = z[i], d = a - zhat[i];
+    xin[(b * 2) * TD + r] = a;
+    xin[(b * 2 + 1) * TD + r] = d * d;
+}
+
+// ------------------------------------------------------------------------------------------------ pool/ReLU/BN backward
+// pass A (grid = B): per-channel sums S1 = sum da, S2 = sum da*xhat over this window, da = dp routed to the argmax cell
+__global__ void __launch_bounds__(256) bn_bwd_stats_kernel(int C, int H, int W, const float* __restrict__ dp, const unsigned char* __restrict__ idx,
+                                                           const float* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           float* __restrict__ part) {
+    __shared__ float red[4];
+    const int Hp = H / 2, Wp = W / 2, b = blockIdx.x, npc = Hp * Wp;
+    for (int c = 0; c < C; ++c) {
+        float s1 = 0.f, s2 = 0.f;
+        const float m = mean[c], rs = rstd[c];
+        for (int r = threadIdx.x; r < npc; r += 256) {
+            const size_t e = ((size_t)b * C + c) * npc + r;
+            const int k = idx[e];
+            if (k < 4) {
+                const int hp = r / Wp, wp = r - hp * Wp;
+                const float yv = y[((size_t)b * C + c) * H * W + (size_t)(2 * hp + (k >> 1)) * W + 2 * wp + (k & 1)];
+                const float g = dp[e];
+                s1 += g; s2 = fmaf(g, (yv - m) * rs, s2);
+            }
+        }
+        const float a = block_sum(s1, red);
+        const float q = block_sum(s2, red);
+        if (threadIdx.x == 0) { part[((size_t)b * C + c) * 2] = a; part[((size_t)b * C + c) * 2 + 1] = q; }
+    }
+}
+__global__ void __launch_bounds__(64) bn_bwd_finalize_kernel(int C, int B, long long n_per_channel, const float* __restrict__ part,
+                                                             float* __restrict__ k1, float* __restrict__ k2, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta) {
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < B; ++b) { s += (double)part[((size_t)b * C + c) * 2]; q += (double)part[((size_t)b * C + c) * 2 + 1]; }
+    dbeta[c] = (float)s; dgamma[c] = (float)q;
+    k1[c] = (float)(s / (double)n_per_channel); k2[c] = (float)(q / (double)n_per_channel);
+}
+// pass B (grid = B): dy = gamma*rstd * (da - k1 - xhat*k2) at EVERY conv-output position
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(int C, int H, int W, const float* __restrict__ dp, const unsigned char* __restrict__ idx,
+                                                           const float* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ k1, const float* __restrict__ k2,
+                                                           float* __restrict__ dy) {
+    const int Hp = H / 2, Wp = W / 2, b = blockIdx.x, HW = H * W;
+    for (int e = threadIdx.x; e < C * HW; e += 256) {
+        const int c = e / HW, r = e - c * HW, h = r / W, w = r - h * W;
+        const int hp = h >> 1, wp = w >> 1;
+        float da = 0.f;
+        if (hp < Hp && wp < Wp) {
+            const size_t pe = ((size_t)b * C + c) * Hp * Wp + (size_t)hp * Wp + wp;
+            if (idx[pe] == ((h & 1) * 2 + (w & 1))) da = dp[pe];
+        }
+        const size_t o = (size_t)b * C * HW + e;
+        const float xh = (y[o] - mean[c]) * rstd[c];
+        dy[o] = gamma[c] * rstd[c] * (da - k1[c] - xh * k2[c]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ conv backward
+// data gradient: dx[ci][h][w] = sum_co sum_k dy[co][h+1-kh][w+1-kw] W[co][ci][kh][kw]      grid = B
+template <int CIN, int COUT>
+__global__ void __launch_bounds__(256) conv3x3_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
+                                                               int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int HW = H * W, b = blockIdx.x, tid = threadIdx.x;
+    float* ds = sm;                          // [COUT][HW]
+    float* ws = sm + COUT * HW;              // [(co*9+k)][CIN]
+    for (int e = tid; e < COUT * HW; e += 256) ds[e] = dy[(size_t)b * COUT * HW + e];
+    for (int e = tid; e < COUT * CIN * 9; e += 256) {           // w[co][ci][k] -> ws[(co*9+k)*CIN + ci]
+        const int co = e / (CIN * 9), r = e - co * CIN * 9, ci = r / 9, k = r - ci * 9;
+        ws[(co * 9 + k) * CIN + ci] = w[e];
+    }
+    __syncthreads();
+    for (int p = tid; p < HW; p += 256) {
+        const int h = p / W, ww = p - h * W;
+        float acc[CIN];
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) acc[ci] = 0.f;
+        for (int co = 0; co < COUT; ++co) {
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int hh = h + 1 - kh, w2 = ww + 1 - kw;
+                    const float v = (hh >= 0 && hh < H && w2 >= 0 && w2 < W) ? ds[co * HW + hh * W + w2] : 0.f;
+                    const float* wr = ws + (co * 9 + kh * 3 + kw) * CIN;
+#pragma unroll
+                    for (int ci = 0; ci < CIN; ci += 4) {
+                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + ci);
+                        acc[ci] = fmaf(v, w4[0], acc[ci]); acc[ci + 1] = fmaf(v, w4[1], acc[ci + 1]);
+                        acc[ci + 2] = fmaf(v, w4[2], acc[ci + 2]); acc[ci + 3] = fmaf(v, w4[3], acc[ci + 3]);
+                    }
+                }
+        }
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) dx[((size_t)b * CIN + ci) * HW + p] = acc[ci];
+    }
+}
+
+// weight gradient partial of one window: part[b][co][ci][k] = sum_p dy[co][p] x[ci][p + off(k)], part[b][W_n + co] = sum_p dy[co][p]
+template <int CIN, int COUT>
+__global__ void __launch_bounds__(256) conv3x3_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part,
+                                                                 int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int HW = H * W, b = blockIdx.x, tid = threadIdx.x;
+    constexpr int NW_ = COUT * CIN * 9;
+    float* ds = sm;                  // [COUT][HW]
+    float* xs = sm + COUT * HW;      // [CIN][HW]
+    for (int e = tid; e < COUT * HW; e += 256) ds[e] = dy[(size_t)b * COUT * HW + e];
+    for (int e = tid; e < CIN * HW; e += 256) xs[e] = x[(size_t)b * CIN * HW + e];
+    __syncthreads();
+    float* out = part + (size_t)b * (NW_ + COUT);
+    for (int e = tid; e < NW_ + COUT; e += 256) {
+        float acc = 0.f;
+        if (e < NW_) {
+            const int co = e / (CIN * 9), r = e - co * CIN * 9, ci = r / 9, k = r - ci * 9, dh = k / 3 - 1, dw = k % 3 - 1;
+            const float* dr = ds + co * HW;
+            const float* xr = xs + ci * HW;
+            const int h_lo = dh < 0 ? 1 : 0, h_hi = dh > 0 ? H - 1 : H, w_lo = dw < 0 ? 1 : 0, w_hi = dw > 0 ? W - 1 : W;
+            for (int h = h_lo; h < h_hi; ++h)
+                for (int w2 = w_lo; w2 < w_hi; ++w2) acc = fmaf(dr[h * W + w2], xr[(h + dh) * W + w2 + dw], acc);
+        } else {
+            const float* dr = ds + (e - NW_) * HW;
+            for (int p = 0; p < HW; ++p) acc += dr[p];
+        }
+        out[e] = acc;
+    }
+}
+
+template <typename K>
+int opt_in_lds(K kern, size_t lds) {
+    SHM_REQUIRE(lds <= 160 * 1024, SHM_EINVAL, "cnn: window needs %zu bytes of LDS (> 160 KiB): T*D too large", lds);
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    return SHM_OK;
+}
+
+}  // namespace
+
+// =================================================================================================== launchers
+int cnn_conv_fwd(int layer, int B, int H, int W, const float* x, const float* w, const float* bias, float* y, float* part, hipStream_t s) {
+    const int HW = H * W;
+    int rc;
+    if (layer == 1) {
+        const size_t lds = sizeof(float) * (((2 * HW + 3) & ~3) + 2 * 9 * 16 + 4);
+        if (part) { if ((rc = opt_in_lds(conv3x3_fwd_kernel<2, 16, true>, lds))) return rc;
+                    hipLaunchKernelGGL((conv3x3_fwd_kernel<2, 16, true>), dim3(B), dim3(256), lds, s, x, w, bias, y, part, H, W); }
+        else { if ((rc = opt_in_lds(conv3x3_fwd_kernel<2, 16, false>, lds))) return rc;
+               hipLaunchKernelGGL((conv3x3_fwd_kernel<2, 16, false>), dim3(B), dim3(256), lds, s, x, w, bias, y, part, H, W); }
+    } else {
+        const size_t lds = sizeof(float) * (((16 * HW + 3) & ~3) + 16 * 9 * 32 + 4);
+        if (part) { if ((rc = opt_in_lds(conv3x3_fwd_kernel<16, 32, true>, lds))) return rc;
+                    hipLaunchKernelGGL((conv3x3_fwd_kernel<16, 32, true>), dim3(B), dim3(256), lds, s, x, w, bias, y, part, H, W); }
+        else { if ((rc = opt_in_lds(conv3x3_fwd_kernel<16, 32, false>, lds))) return rc;
+               hipLaunchKernelGGL((conv3x3_fwd_kernel<16, 32, false>), dim3(B), dim3(256), lds, s, x, w, bias, y, part, H, W); }
+    }
+    SHM_LAUNCH_CHECK();
+    return SHM_OK;
+}
+int cnn_bn_finalize(int C, int B, long long n, int train, const float* part, const float* gamma, const float* beta, float* run_mean,
+                    float* run_var, float* mean, float* rstd, float* scale, float* shift, hipStream_t s) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, s, C, B, n, train, part, gamma, beta, run_mean, run_var, mean, rstd, scale, shift);
+    SHM_LAUNCH_CHECK();
+    return SHM_OK;
+}
+int cnn_bn_relu_pool(int B, int C, int H, int W, const float* y, const float* scale, const float* shift, float* out, unsigned char* idx, hipStream_t s) {
+    hipLaunchKernelGGL(bn_relu_pool_kernel, dim3(B), dim3(256), 0, s, C, H, W, y, scale, shift, out, idx);
+    SHM_LAUNCH_CHECK();
+    return SHM_OK;
+}
+int cnn_linear_fwd(int B, int F, int O, const float* in, const float* Wt, const float* bias, float* pre, float* out, int relu, float drop_p,
+                   uint64_t seed, hipStream_t s) {
+    hipLaunchKernelGGL(linear_fwd_kernel, dim3(ceil_div(O, 32), ceil_div(B, 32)), dim3(256), 0, s, B, F, O, in, Wt, bias, pre, out, relu, drop_p,
+                       (unsigned long long)seed);
+    SHM_LAUNCH_CHECK();
+    return SHM_OK;
+}
+int cnn_linear_bwd_dx(int B, int F, int O, const float* dy, const float* Wt, const float* pre, float* dx, float drop_p, uint64_t seed, hipStream_t s) {
+    const size_t n = (size_t)B * F;
+    hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, B, F, O, dy, Wt, pre, dx, drop_p, (unsigned long long)seed);
+    SHM_LAUNCH_CHECK();
+    return SHM_OK;
+}
+int cnn_ce_loss(int B, int NC, const float* logits, const long long* labels, float* dlogits, float* loss, hipStream_t s) {
+    hipLaunchKernelGGL(ce_loss_kernel, dim3(1), dim3(256), 0, s, B, NC, logits, labels, dlogits, loss);
+    SHM_LAUNCH_CHECK();
+    return SHM_OK;
+}
+int cnn_softmax_argmax(int B, int NC, const float* logits, long long* cls, float* p1, hipStream_t s) {
+    hipLaunchKernelGGL(softmax_argmax_kernel, dim3(ceil_div(B, 256)), dim3(256), 0, s, B, NC, logits, cls, p1);
+    SHM_LAUNCH_CHECK();
+    return SHM_OK;
+}
+int cnn_build_input(int B, int TD, const float* z, const float* zhat, float* xin, hipStream_t s) {
+    const size_t n = (size_t)B * TD;
+    hipLaunchKernelGGL(build_input_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, B, TD, z, zhat, xin);
+    SHM_LAUNCH_CHECK();
+    return SHM_OK;
+}
+int cnn_bn_bwd(int B, int C, int H, int W, const float* dp, const unsigned char* idx, const float* y, const float* mean, const float* rstd,
+               const float* gamma, float* part, float* k1, float* k2, float* dgamma, float* dbeta, float* dy, hipStream_t s) {
+    hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(B), dim3(256), 0, s, C, H, W, dp, idx, y, mean, rstd, part);
+    SHM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(64), 0, s, C, B, (long long)B * H * W, part, k1, k2, dgamma, dbeta);
+    SHM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(B), dim3(256), 0, s, C, H, W, dp, idx, y, mean, rstd, gamma, k1, k2, dy);
+    SHM_LAUNCH_CHECK();
+    return SHM_OK;
+}
+int cnn_conv_bwd_data2(int B, int H, int W, const float* dy, const float* w, float* dx, hipStream_t s) {
+    const size_t lds = sizeof(float) * ((size_t)32 * H * W + 32 * 9 * 16);
+    int rc = opt_in_lds(conv3x3_bwd_data_kernel<16, 32>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((conv3x3_bwd_data_kernel<16, 32>), dim3(B), dim3(256), lds, s, dy, w, dx, H, W);
+    SHM_LAUNCH_CHECK();
+    return SHM_OK;
+}
+int cnn_conv_bwd_weight(int layer, int B, int H, int W, const float* dy, const float* x, float* part, hipStream_t s) {
+    int rc;
+    if (layer == 1) {
+        const size_t lds = sizeof(float) * ((size_t)(16 + 2) * H * W);
+        if ((rc = opt_in_lds(conv3x3_bwd_weight_kernel<2, 16>, lds))) return rc;
+        hipLaunchKernelGGL((conv3x3_bwd_weight_kernel<2, 16>), dim3(B), dim3(256), lds, s, dy, x, part, H, W);
+    } else {
+        const size_t lds = sizeof(float) * ((size_t)(32 + 16) * H * W);
+        if ((rc = opt_in_lds(conv3x3_bwd_weight_kernel<16, 32>, lds))) return rc;
+        hipLaunchKernelGGL((conv3x3_bwd_weight_kernel<16, 32>), dim3(B), dim3(256), lds, s, dy, x, part, H, W);
+    }
+    SHM_LAUNCH_CHECK();
+    return SHM_OK;
+}
+
+}  // namespace shm

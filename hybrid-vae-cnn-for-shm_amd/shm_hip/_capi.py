@@ -19,6 +19,11 @@ class VaeConfig(C.Structure):
                 ("dropout", C.c_float)]
 
 
+class CnnConfig(C.Structure):
+    _fields_ = [("in_channels", C.c_int32), ("num_classes", C.c_int32), ("seq_len", C.c_int32),
+                ("num_features", C.c_int32), ("dropout", C.c_float)]
+
+
 class TensorDesc(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("offset", C.c_int64), ("ndim", C.c_int32), ("shape", C.c_int32 * 4)]
 
@@ -31,6 +36,7 @@ def _load():
     lib = C.CDLL(str(_LIB_PATH))
     vp, f32p = C.c_void_p, C.c_void_p
     cfgp = C.POINTER(VaeConfig)
+    ccfgp = C.POINTER(CnnConfig)
     sig = {
         "shm_last_error": (C.c_char_p, []),
         "shm_version": (C.c_int, []),
@@ -46,6 +52,16 @@ def _load():
         "shm_adam_scratch_bytes": (C.c_size_t, [C.c_int64]),
         "shm_adam_step": (C.c_int, [C.c_int64, f32p, f32p, f32p, f32p, C.c_int32, C.c_float, C.c_float, C.c_float,
                                     C.c_float, C.c_float, C.c_float, C.c_float, vp, f32p, vp]),
+        "shm_cnn_param_count": (C.c_int64, [ccfgp]),
+        "shm_cnn_param_layout": (C.c_int, [ccfgp, C.POINTER(TensorDesc), C.c_int]),
+        "shm_cnn_plan_create": (C.c_int, [ccfgp, C.c_int32, C.c_int32, C.POINTER(vp)]),
+        "shm_cnn_plan_destroy": (None, [vp]),
+        "shm_cnn_plan_workspace_bytes": (C.c_size_t, [vp]),
+        "shm_cnn_forward": (C.c_int, [vp, f32p, f32p, f32p, f32p, C.c_int32, C.c_uint64, vp, vp]),
+        "shm_cnn_loss": (C.c_int, [vp, vp, f32p, vp, vp]),
+        "shm_cnn_backward": (C.c_int, [vp, f32p, f32p, f32p, f32p, vp, vp]),
+        "shm_cnn_build_input": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, f32p, f32p, f32p, vp]),
+        "shm_cnn_predict": (C.c_int, [C.c_int32, C.c_int32, f32p, vp, f32p, vp]),
         "shm_profile_begin": (C.c_int, []),
         "shm_profile_end": (C.c_int, [C.c_char_p, C.c_size_t]),
         "shm_dropout_keep_mask": (None, [C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, vp]),
@@ -80,3 +96,13 @@ def param_layout(cfg: VaeConfig):
     total = lib.shm_vae_param_count(C.byref(cfg))
     out = [(d.name.decode(), int(d.offset), tuple(int(d.shape[i]) for i in range(d.ndim))) for d in arr]
     return out, int(total)
+
+
+def cnn_param_layout(cfg: CnnConfig):
+    n = lib.shm_cnn_param_layout(C.byref(cfg), None, 0)
+    if n < 0:
+        check(n, "shm_cnn_param_layout")
+    arr = (TensorDesc * n)()
+    lib.shm_cnn_param_layout(C.byref(cfg), arr, n)
+    total = lib.shm_cnn_param_count(C.byref(cfg))
+    return [(d.name.decode(), int(d.offset), tuple(int(d.shape[i]) for i in range(d.ndim))) for d in arr], int(total)

@@ -112,3 +112,50 @@ class VAETrainer:
         recon = score.mean()
         kl = -0.5 * torch.mean(1.0 + lv - mu.pow(2) - lv.exp())
         return torch.stack([recon + kl_w * kl, recon, kl])
+
+
+class CNNTrainer:
+    """Fused CNN train step (reference 4DOF/Scripts/05_train_cnn.py:270-276): forward (batch-stat BatchNorm, dropout) ->
+    CrossEntropy -> backward -> [flat gradient all-reduce] -> Adam(lr 1e-4, wd 5e-5), no clipping.  BatchNorm statistics stay
+    per-rank under data parallelism (plain DDP semantics)."""
+
+    def __init__(self, model, lr=1e-4, weight_decay=5e-5, betas=(0.9, 0.999), eps=1e-8, seed=42, group=None, sync_params=True):
+        self.model = model
+        self.engine = model._engine
+        self._named, self._bufs = dict(model.named_parameters()), dict(model.named_buffers())
+        self.flat = self.engine.bind(self._named, self._bufs)
+        dev, n = self.flat.device, self.engine.n_flat
+        self.grads = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.scratch = torch.zeros(int(lib.shm_adam_scratch_bytes(n)), dtype=torch.uint8, device=dev)
+        self.stats = torch.zeros(2, dtype=torch.float32, device=dev)      # loss, grad_norm
+        self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
+        self.step_count = 0
+        self.comm = FlatAllReduce(group)
+        rank = self.comm.dist.get_rank(group) if self.comm.world > 1 else 0
+        self.seed = seed + 7919 * rank
+        if sync_params:
+            self.comm.broadcast(self.flat, 0)
+
+    def step(self, x: torch.Tensor, y: torch.Tensor, drop_seed: int | None = None):
+        """One optimiser step on the local shard; returns the device tensor [loss, grad_norm]."""
+        eng = self.engine
+        if eng.bind(self._named, self._bufs) is not self.flat:
+            raise RuntimeError("model parameters were re-allocated after the trainer was built")
+        eng.cfg.dropout = float(self.model.fc1[2].p)
+        self.step_count += 1
+        if drop_seed is None:
+            drop_seed = (self.seed << 20) + self.step_count
+        _, pl, xc = eng.forward(x, training_plan=True, train_mode=True, drop_seed=drop_seed)
+        eng.loss(pl, y.contiguous().to(torch.int64), self.stats)
+        eng.backward(pl, xc, self.grads)
+        scale = self.comm(self.grads)
+        b1, b2 = self.betas
+        check(lib.shm_adam_step(C.c_int64(eng.n_flat), _ptr(self.flat), _ptr(self.grads), _ptr(self.exp_avg),
+                                _ptr(self.exp_avg_sq), self.step_count, C.c_float(self.lr), C.c_float(b1), C.c_float(b2),
+                                C.c_float(self.eps), C.c_float(self.wd), C.c_float(0.0), C.c_float(scale),
+                                _ptr(self.scratch), C.c_void_p(self.stats.data_ptr() + 4), _stream()), "shm_adam_step")
+        self.model.conv1[1].num_batches_tracked += 1
+        self.model.conv2[1].num_batches_tracked += 1
+        return self.stats

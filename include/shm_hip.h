@@ -102,6 +102,42 @@ int  shm_adam_step(int64_t n, float* params, float* grads, float* exp_avg, float
                    int32_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
                    float max_norm, float grad_scale, void* scratch, float* out_norm, void* stream);
 
+/* ======================================================================================================
+ * CNN fault classifier (reference 4DOF/Scripts/Models/cnn_model.py:14-51): Conv2d(C,16,3,p1)+BatchNorm2d+ReLU+MaxPool2d(2),
+ * Conv2d(16,32,3,p1)+BatchNorm2d+ReLU+MaxPool2d(2), Flatten, Linear(F,128)+ReLU+Dropout, Linear(128,classes);
+ * F = 32*(T/4)*(D/4) (cnn_model.py:30 hard-codes 32*25*3 for T=100, D=12).  fp32 throughout.
+ * Parameters: flat fp32 buffer in state_dict order of the 12 learnable tensors (shm_cnn_param_layout);
+ * BatchNorm buffers travel separately: running[0:16]=conv1 mean, [16:32]=conv1 var, [32:64]=conv2 mean, [64:96]=conv2 var. */
+typedef struct shm_cnn_config {
+    int32_t in_channels;   /* 2: window + squared VAE residual (05_train_cnn.py:137-138) */
+    int32_t num_classes;   /* 2 */
+    int32_t seq_len;       /* T  (cnn_model.py:4 SEQ_LEN) */
+    int32_t num_features;  /* D  (cnn_model.py:5 NUM_FEATURES) */
+    float   dropout;       /* fc1 Dropout p (train mode) */
+} shm_cnn_config;
+typedef struct shm_cnn_plan shm_cnn_plan;
+
+int64_t shm_cnn_param_count(const shm_cnn_config* cfg);
+int  shm_cnn_param_layout(const shm_cnn_config* cfg, shm_tensor_desc* out, int max);
+int  shm_cnn_plan_create(const shm_cnn_config* cfg, int32_t B, int32_t training, shm_cnn_plan** out);
+void shm_cnn_plan_destroy(shm_cnn_plan* plan);
+size_t shm_cnn_plan_workspace_bytes(const shm_cnn_plan* plan);
+
+/* CNN.forward (cnn_model.py:45-51).  x[B,C,T,D] NCHW -> logits[B,classes].  train_mode != 0: BatchNorm uses batch
+ * statistics and updates `running` (momentum 0.1, unbiased variance), Dropout is active (counter RNG, drop_seed) and, on a
+ * training plan, the state backward needs is kept.  train_mode == 0: running statistics, no dropout (model.eval()). */
+int  shm_cnn_forward(shm_cnn_plan* plan, const float* params, float* running, const float* x, float* logits,
+                     int32_t train_mode, uint64_t drop_seed, void* workspace, void* stream);
+/* nn.CrossEntropyLoss() (05_train_cnn.py:257,274): loss (device, 1 float) and dLoss/dlogits left in the workspace. */
+int  shm_cnn_loss(shm_cnn_plan* plan, const int64_t* labels, float* loss, void* workspace, void* stream);
+/* loss.backward() (05_train_cnn.py:275).  d_logits NULL: use the one left by shm_cnn_loss.  grads: flat fp32, overwritten. */
+int  shm_cnn_backward(shm_cnn_plan* plan, const float* params, const float* x, const float* d_logits, float* grads,
+                      void* workspace, void* stream);
+/* xin = stack([z, (z - zhat)^2], dim=1)  (05_train_cnn.py:137-138, 06_test_full_pipeline.py:364-365); z, zhat [B,T,D]. */
+int  shm_cnn_build_input(int32_t B, int32_t T, int32_t D, const float* z, const float* zhat, float* xin, void* stream);
+/* argmax(logits, 1) and softmax(logits, 1)[:, 1]  (06_test_full_pipeline.py:367-371); either output may be NULL. */
+int  shm_cnn_predict(int32_t B, int32_t num_classes, const float* logits, int64_t* cls, float* p1, void* stream);
+
 /* Per-kernel timing with HIP events recorded on the launch stream (used by bench.py for the roofline line).
  * shm_profile_begin() arms it for the calling thread; shm_profile_end() synchronises the device and writes a JSON
  * object {"lstm_fwd.enc0": {"calls": n, "ms": total}, ...} into json[cap]. */
