@@ -67,7 +67,7 @@ def test_train_steps_match_reference(name, fused):
             loss = float(l)
         assert abs(loss - float(g[f"loss{s}"])) < 1e-5, (loss, float(g[f"loss{s}"]))
         if s == 0:
-            rep = {k: maxdiff(grads[k], v) / (np.abs(v).max() + 1e-30) for k, v in split_prefix(g, "g0.").items() if k not in CONV_BIAS}
+            rep = {k: float(maxdiff(grads[k], v) / (np.abs(v).max() + 1e-30)) for k, v in split_prefix(g, "g0.").items() if k not in CONV_BIAS}
             print(name, "fused" if fused else "dropin", "grad rel err", json.dumps({k: round(v, 7) for k, v in rep.items()}))
             assert max(rep.values()) < 2e-4, rep
             for k in CONV_BIAS:                      # true gradient is 0 (BatchNorm cancels the bias): only noise on both sides
