@@ -35,16 +35,19 @@ def alg_flops_forward_per_window():
     return F - 2 * G * H * (T - 1)
 
 
-def kernel_alg_flops(name, B):
-    """Algorithmic FLOPs of ONE launch of a profiled kernel (MFMA contractions only; pointwise excluded)."""
+def kernel_alg_flops(name, B, bf16=False):
+    """Algorithmic FLOPs of ONE launch of a profiled kernel (MFMA contractions only; pointwise excluded).
+    In the bf16 path dx = dpre.W_ih is a separate time-parallel GEMM (dx_gemm.*); in the fp32 path it is inside lstm_bwd."""
     G = 4 * H
     kind, _, inst = name.partition(".")
     if kind == "lstm_fwd":
         k_in = {"enc0": D, "enc1": H, "dec0": 0, "dec1": H}[inst]          # dec0: constant input, projected once
         return B * T * 2 * G * (k_in + H) + (B * 2 * G * H if inst == "dec0" else 0)
     if kind == "lstm_bwd":
-        k_dx = {"enc0": 0, "enc1": H, "dec0": 0, "dec1": H}[inst]          # dx only for layers with a layer below
+        k_dx = 0 if bf16 else {"enc0": 0, "enc1": H, "dec0": 0, "dec1": H}[inst]   # dx only for layers with a layer below
         return B * T * 2 * G * (H + k_dx)
+    if kind == "dx_gemm":
+        return B * T * 2 * G * H
     if kind == "dw_gemm":
         k_in = {"enc0": D, "enc1": H, "dec0": 0, "dec1": H, "out": 0}[inst]
         if inst == "out":
@@ -173,8 +176,9 @@ def main():
         prof = json.loads(buf.value.decode())
         log("kernel profile: " + json.dumps(prof))
         per = {k: v["ms"] / v["calls"] for k, v in prof.items()}
-        dom = max((k for k in per if kernel_alg_flops(k, B_PER_GPU) > 0), key=lambda k: per[k])
-        fl = kernel_alg_flops(dom, B_PER_GPU)
+        is_bf = args.precision == "bf16"
+        dom = max((k for k in per if kernel_alg_flops(k, B_PER_GPU, is_bf) > 0), key=lambda k: per[k])
+        fl = kernel_alg_flops(dom, B_PER_GPU, is_bf)
         achieved = fl / (per[dom] * 1e-3) / 1e12
         peak = PEAK_TFLOPS[dt_key]
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",

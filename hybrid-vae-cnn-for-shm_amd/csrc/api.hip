@@ -59,7 +59,6 @@ struct shm_vae_plan {
     size_t h_last, eps, y, xhat, rstd, mu, lv, z, h0, dpre_l2h, dmu, dlv, dyx, dy, dh_last, dh0;
     size_t recon, score, d_recon, d_mu, d_lv, dpre_seq, dx_seq, dpre_tsum, gemm_partial, colsum_scratch;
     size_t gemm_partial_elems;
-    size_t fuse_w;          // per-tile partials of the narrow product folded into the bf16 encoder-L0 backward kernel
     size_t narrow_scratch;  // block partials of narrow_tn
     size_t params_copy;     // flat fp32 copy of the parameters (head / output layer read them unpacked)
     size_t ws_bytes;
@@ -242,7 +241,6 @@ extern "C" int shm_vae_plan_create(const shm_vae_config* cfg, int32_t B, int32_t
         upd((int)BT, H, D); upd((int)BT, 4 * H, H); upd((int)BT, 4 * H, D); upd(B, 4 * H, H); upd(B, H, Z); upd(B, Z, H);
         if (bf) { const size_t e = gemm_tn_bf16_partial_elems((int)BT, 4 * H, H); if (e > gp) gp = e; }
         p->gemm_partial_elems = gp;
-        p->fuse_w = take(tiles * 4 * H * (size_t)(D > 4 ? 4 : D));
         p->narrow_scratch = take(narrow_tn_scratch_elems(4 * H, D));
         p->gemm_partial = take(gp > 0 ? gp : 1);
         size_t cs = colsum_scratch_elems((int)BT, D);
@@ -456,16 +454,18 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
                 a.dpre_seq = at<bf16_t>(ws, p->dpre_seq); a.dpre_tsum = dpre_tsum; a.dx_seq = dx_seq;
                 a.B = B; a.T = T; a.In = st[l].In;
                 a.drop_p = l > 0 ? drop : 0.f; a.drop_seed = p->drop_seed; a.drop_stack = stack;
-                const int ntile = ceil_div(B, 16);
-                const bool fuse_x = false;   // in-kernel dW_ih (FUSE = 2) measured slower than narrow_tn: +0.26 ms vs -0.15 ms
-                if (fuse_x) { a.fuse = 2; a.x = x0; a.Dx = D; a.fuse_w = at<float>(ws, p->fuse_w); }
                 int r;
                 {
                     KernelTimer kt(nm, s);
                     r = launch_lstm_bwd_bf16(H, a, s);
-                    if (!r && fuse_x) r = launch_reduce_partials(a.fuse_w, ntile, (size_t)G * D, grads + st[l].w_ih, nullptr, s);
                 }
                 if (r) return r;
+                if (l > 0) {
+                    char dnm[32];
+                    snprintf(dnm, sizeof(dnm), "dx_gemm.%s%d", stack == 0 ? "enc" : "dec", l);
+                    KernelTimer kt(dnm, s);
+                    if ((r = launch_dx_gemm_bf16(H, a, s))) return r;
+                }
                 KernelTimer kt(gnm, s);
                 const void* dps = at<char>(ws, p->dpre_seq);
                 if ((r = gemm_bf(dps, G, G, at<char>(ws, st[l].h_seq), H, H, BT, grads + st[l].w_hh, T, 0.f, 0))) return r;
@@ -473,7 +473,7 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
                     if ((r = gemm_bf(dps, G, G, at<char>(ws, st[l - 1].h_seq), H, H, BT, grads + st[l].w_ih, 0, drop, stack))) return r;
                 } else if (st[l].in_const) {
                     if ((r = gemm(dpre_tsum, G, G, hb.h0, H, H, B, grads + st[l].w_ih, 0, 0, 0.f, 0))) return r;
-                } else if (!fuse_x) {
+                } else {
                     if ((r = launch_narrow_tn(dps, 1, G, G, x0, D, BT, grads + st[l].w_ih, 1, nullptr, at<float>(ws, p->narrow_scratch), s))) return r;
                 }
                 if ((r = launch_colsum(dpre_tsum, G, B, G, grads + st[l].b_ih, grads + st[l].b_hh, cs, s))) return r;

@@ -125,12 +125,9 @@ struct LstmBwdArgsB {
     float* dx_seq;          // [B,T,In] fp32
     int B, T, In, Dy, need_dx;
     float drop_p; uint64_t drop_seed; uint32_t drop_stack;
-    // fuse = 2: dW_ih partials [tile][4H][Dx] accumulated in-kernel from x [B,T,Dx] (Dx <= 4, layer without dx)
-    int fuse, Dx;
-    const float* x;
-    float* fuse_w;
 };
-int launch_lstm_bwd_bf16(int H, const LstmBwdArgsB& a, hipStream_t s);
+int launch_lstm_bwd_bf16(int H, const LstmBwdArgsB& a, hipStream_t s);      // recurrent part: dpre_seq, dpre_tsum
+int launch_dx_gemm_bf16(int H, const LstmBwdArgsB& a, hipStream_t s);       // time-parallel part: dx_seq = dpre_seq . W_ih
 
 struct GemmTnArgsB {
     const void* A; int lda;        // [R, M] bf16

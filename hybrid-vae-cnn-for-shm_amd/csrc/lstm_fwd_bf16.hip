@@ -60,49 +60,52 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
     const int my_h_off = ((u0 / KQH) * 16 + j) * RSH + (u0 % KQH);
     const int my_x_off = ((u0 / KQX) * 16 + j) * RSX + (u0 % KQX);      // only meaningful when In == H
 
-    // ---- x staging
-    bf16x4 xr = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
-    float xs[2] = {0.f, 0.f};             // XF32 path: <= 2 scalars per thread (16*In <= 2*NTHR, checked on host)
-    auto x_load = [&](int t) {
+    // ---- x staging: x_{t+1..t+3} travel in three rotating register slots (the loop below is unrolled x3 so the slot index
+    // is static); a slot is committed to LDS one step before it is consumed and refilled 4 steps ahead, so the global-load
+    // latency (and the in-order vmcnt queue behind this step's stores) is covered by three full steps.
+    struct XSlot { bf16x4 v; float s0, s1; };
+    auto x_fetch = [&](XSlot& X, int t) {
+        if (a.in_const || t >= T) return;
         if constexpr (XF32) {
             const float* xin = reinterpret_cast<const float*>(a.in);
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int e = tid + it * NTHR;
-                xs[it] = 0.f;
-                if (e < 16 * In) {
-                    const int jj = e / In, kk = e - jj * In, bb = b0 + jj;
-                    if (bb < B) xs[it] = xin[((size_t)bb * T + t) * In + kk];
-                }
+            X.s0 = X.s1 = 0.f;
+            if (tid < 16 * In) {
+                const int jj = tid / In, kk = tid - jj * In, bb = b0 + jj;
+                if (bb < B) X.s0 = xin[((size_t)bb * T + t) * In + kk];
+            }
+            if (tid + NTHR < 16 * In) {
+                const int e = tid + NTHR, jj = e / In, kk = e - jj * In, bb = b0 + jj;
+                if (bb < B) X.s1 = xin[((size_t)bb * T + t) * In + kk];
             }
         } else {
             const bf16_t* xin = reinterpret_cast<const bf16_t*>(a.in);
+            X.v = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
             if (bvalid) {
                 const size_t idx = ((size_t)b * T + t) * H + u0;
-                xr = *reinterpret_cast<const bf16x4*>(xin + idx);
+                X.v = *reinterpret_cast<const bf16x4*>(xin + idx);
                 if (DROP) {
-                    f32x4 v = cvt_f32x4(xr);
+                    f32x4 v = cvt_f32x4(X.v);
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         v[e] = drop_hash(a.drop_seed, a.drop_stack, (uint32_t)(idx + e)) >= thr ? v[e] * dscale : 0.f;
-                    xr = cvt_bf16x4(v);
+                    X.v = cvt_bf16x4(v);
                 }
             }
         }
     };
-    auto x_store = [&](int buf) {
+    auto x_commit = [&](const XSlot& X, int buf) {
         bf16_t* xl = x_lds + buf * XBUF;
         if constexpr (XF32) {
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int e = tid + it * NTHR;
-                if (e < 16 * In) {
-                    const int jj = e / In, kk = e - jj * In;
-                    xl[((kk / KQX) * 16 + jj) * RSX + (kk % KQX)] = (bf16_t)xs[it];
-                }
+            if (tid < 16 * In) {
+                const int jj = tid / In, kk = tid - jj * In;
+                xl[((kk / KQX) * 16 + jj) * RSX + (kk % KQX)] = (bf16_t)X.s0;
+            }
+            if (tid + NTHR < 16 * In) {
+                const int e = tid + NTHR, jj = e / In, kk = e - jj * In;
+                xl[((kk / KQX) * 16 + jj) * RSX + (kk % KQX)] = (bf16_t)X.s1;
             }
         } else {
-            *reinterpret_cast<bf16x4*>(xl + my_x_off) = xr;
+            *reinterpret_cast<bf16x4*>(xl + my_x_off) = X.v;
         }
     };
 
@@ -138,8 +141,9 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
         for (int g = 0; g < 4; ++g) xproj[g] = bias4[g];
         mma_x(xproj, x_lds);
     } else {
-        x_load(0);
-        x_store(0);
+        XSlot X;
+        x_fetch(X, 0);
+        x_commit(X, 0);
         __syncthreads();
     }
 
@@ -147,9 +151,9 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
     bf16_t* svg = a.sv_g ? a.sv_g + (((size_t)tile * T * NW + ht) * 64 + lane) * 16 : nullptr;
     float* svc = a.sv_c ? a.sv_c + (((size_t)tile * T * NW + ht) * 64 + lane) * 4 : nullptr;
 
-    for (int t = 0; t < T; ++t) {
+    // X: slot holding x_{t+1}; committed at the end of the step and refilled with x_{t+4}
+    auto step = [&](XSlot& X, int t) {
         const int cur = t & 1;
-        if (!a.in_const && t + 1 < T) x_load(t + 1);
         f32x4 acc[4];
         if (a.in_const) {
 #pragma unroll
@@ -173,7 +177,8 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
         }
         const bf16x4 hb = cvt_bf16x4(h4);
         *reinterpret_cast<bf16x4*>(h_lds + (cur ^ 1) * HBUF + my_h_off) = hb;
-        if (!a.in_const && t + 1 < T) x_store(cur ^ 1);
+        if (!a.in_const && t + 1 < T) x_commit(X, cur ^ 1);
+        x_fetch(X, t + 4);
         if (a.h_seq && bvalid) *reinterpret_cast<bf16x4*>(a.h_seq + ((size_t)b * T + t) * H + u0) = hb;
         if (svg) {
             bf16_t* p = svg + (size_t)t * NW * 64 * 16;
@@ -186,6 +191,13 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
             *reinterpret_cast<f32x4*>(svc + (size_t)t * NW * 64 * 4) = c;
         }
         __syncthreads();
+    };
+    XSlot X0, X1, X2;
+    x_fetch(X0, 1); x_fetch(X1, 2); x_fetch(X2, 3);
+    for (int t = 0; t < T; t += 3) {
+        step(X0, t);
+        if (t + 1 < T) step(X1, t + 1);
+        if (t + 2 < T) step(X2, t + 2);
     }
     if (a.h_last && bvalid) *reinterpret_cast<f32x4*>(a.h_last + (size_t)b * H + u0) = h4;
 }
