@@ -206,7 +206,7 @@ extern "C" int shm_vae_plan_create(const shm_vae_config* cfg, int32_t B, int32_t
             if (bf) {
                 li.Wx = take_bytes(2 * fwd_pack_elems_bf16(H, li.In));
                 li.Wh = take_bytes(2 * fwd_pack_elems_bf16(H, H));
-                li.h_seq = take_bytes(2 * BT * H);
+                li.h_seq = take_bytes(2 * tiles * 16 * T * H);            // whole tiles: unconditional stores in the kernel
                 if (training) {
                     li.WhT = take_bytes(2 * bwd_pack_elems_bf16(H, H));
                     if (l > 0) li.WxT = take_bytes(2 * bwd_pack_elems_bf16(H, li.In));
@@ -234,7 +234,7 @@ extern "C" int shm_vae_plan_create(const shm_vae_config* cfg, int32_t B, int32_t
         p->dpre_l2h = take((size_t)B * H); p->dmu = take((size_t)B * Z); p->dlv = take((size_t)B * Z);
         p->dyx = take((size_t)B * H); p->dy = take((size_t)B * H); p->dh_last = take((size_t)B * H); p->dh0 = take((size_t)B * H);
         p->recon = take(BT * D); p->d_recon = take(BT * D); p->d_mu = take((size_t)B * Z); p->d_lv = take((size_t)B * Z);
-        p->dpre_seq = bf ? take_bytes(2 * BT * 4 * H) : take(BT * 4 * H);
+        p->dpre_seq = bf ? take_bytes(2 * tiles * 16 * T * 4 * H) : take(BT * 4 * H);   // bf16: whole tiles (unconditional stores)
         p->dx_seq = take(BT * H); p->dpre_tsum = take((size_t)B * 4 * H);
         size_t gp = 0;
         auto upd = [&](int R, int M, int N) { const size_t e = gemm_tn_partial_elems(R, M, N); if (e > gp) gp = e; };

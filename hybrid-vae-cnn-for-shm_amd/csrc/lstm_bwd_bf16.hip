@@ -18,10 +18,16 @@ namespace {
 struct Prefetch {            // operands of one time step, fetched PD = 3 steps ahead
     bf16x8 lo, hi;           // gates i,f | g,o of the lane's 4 units (bf16)
     f32x4 cp;                // c_{t-1}
-    f32x4 dha;               // gradient arriving on h_t from above (layer above / output layer / h_T)
+    f32x4 up;                // DH == 1: dh_seq[b,t,u0..u0+3];  DH == 2: dy[b,t,0..3] (raw, multiplied by W_out at use)
 };
 
-template <int H>
+// DH: where the gradient on h_t comes from besides the recurrence — 0: nothing (encoder top layer: only h_T, folded into
+// the initial dh_rec), 1: dh_seq from the layer above, 2: output layer with exactly 4 channels, dy[B,T,4] x W_out (top
+// decoder layer at the north-star shape; raw dy is prefetched, the product is formed at use), 3: output layer with any
+// other channel count (dy.W_out evaluated inside the fetch: synchronous fallback for the reference-native shapes).
+// The time loop is branch-free: loads are clamped, never predicated, and T % 3 steps are peeled, so that the compiler can
+// count the loads in flight across the back-edge instead of draining them (s_waitcnt vmcnt(0)) at every loop header.
+template <int H, int DH>
 __global__ void __launch_bounds__(4 * H) lstm_bwd_bf16_kernel(LstmBwdArgsB a) {
     constexpr int NW = H / 16, NTHR = 64 * NW;
     constexpr int KS = H / 8;                      // k-steps of 32 over K = 4H
@@ -35,9 +41,11 @@ __global__ void __launch_bounds__(4 * H) lstm_bwd_bf16_kernel(LstmBwdArgsB a) {
     const int tid = threadIdx.x, lane = tid & 63, ht = tid >> 6, q = lane >> 4, j = lane & 15;
     const int tile = blockIdx.x, b0 = tile * 16, b = b0 + j;
     const bool bvalid = b < B;
+    const int bc = bvalid ? b : B - 1;             // clamped row for loads; its contribution is zeroed through vmask
+    const float vmask = bvalid ? 1.f : 0.f;
     const int u0 = ht * 16 + q * 4;
 
-    if (a.dy)
+    if (DH >= 2)
         for (int e = tid; e < Dy * H; e += NTHR) wo_lds[e] = a.Wout[e];
 
     bf16x8 whT[KS];
@@ -50,27 +58,21 @@ __global__ void __launch_bounds__(4 * H) lstm_bwd_bf16_kernel(LstmBwdArgsB a) {
     const bf16_t* svg = a.sv_g + (((size_t)tile * T * NW + ht) * 64 + lane) * 16;
     const float* svc = a.sv_c + (((size_t)tile * T * NW + ht) * 64 + lane) * 4;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    const bf16x8 zero8 = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
 
     auto fetch = [&](Prefetch& P, int t) {
-        if (t < 0) { P.lo = zero8; P.hi = zero8; P.cp = zero4; P.dha = zero4; return; }
-        const bf16_t* p = svg + (size_t)t * NW * 64 * 16;
+        const int tc = t < 0 ? 0 : t;                                  // clamp: steps < 0 are fetched but never used
+        const bf16_t* p = svg + (size_t)tc * NW * 64 * 16;
         P.lo = *reinterpret_cast<const bf16x8*>(p);
         P.hi = *reinterpret_cast<const bf16x8*>(p + 8);
-        P.cp = t > 0 ? *reinterpret_cast<const f32x4*>(svc + (size_t)(t - 1) * NW * 64 * 4) : zero4;
-        f32x4 d = zero4;
-        if (bvalid) {
-            const size_t row = (size_t)b * T + t;
-            if (a.dh_seq) d = *reinterpret_cast<const f32x4*>(a.dh_seq + row * H + u0);
-            if (a.dy) {
-                for (int dd = 0; dd < Dy; ++dd) {
-                    const float dyv = a.dy[row * Dy + dd];
-                    d += dyv * *reinterpret_cast<const f32x4*>(wo_lds + dd * H + u0);
-                }
-            }
-            if (a.dh_last && t == T - 1) d += *reinterpret_cast<const f32x4*>(a.dh_last + (size_t)b * H + u0);
-        }
-        P.dha = d;
+        P.cp = *reinterpret_cast<const f32x4*>(svc + (size_t)(tc > 0 ? tc - 1 : 0) * NW * 64 * 4);
+        const size_t row = (size_t)bc * T + tc;
+        if constexpr (DH == 1) P.up = *reinterpret_cast<const f32x4*>(a.dh_seq + row * H + u0);
+        else if constexpr (DH == 2) P.up = *reinterpret_cast<const f32x4*>(a.dy + row * 4);       // Dy == 4 exactly
+        else if constexpr (DH == 3) {
+            f32x4 d = zero4;
+            for (int dd = 0; dd < Dy; ++dd) d += a.dy[row * Dy + dd] * *reinterpret_cast<const f32x4*>(wo_lds + dd * H + u0);
+            P.up = d;
+        } else P.up = zero4;
     };
 
     f32x4 dc = zero4, dh_rec = zero4, c_cur;
@@ -78,17 +80,27 @@ __global__ void __launch_bounds__(4 * H) lstm_bwd_bf16_kernel(LstmBwdArgsB a) {
 
     // one time step; P holds this step's operands and is refilled with step t-3 once they are consumed
     auto step = [&](Prefetch& P, int t) {
+        // Pin the consumption point of this slot: without it the compiler hoists the bf16->f32 unpacking of the LATER slots
+        // into this step, i.e. touches registers whose loads are still in flight and turns the counted waits into a drain.
+        asm volatile("" : "+v"(P.lo), "+v"(P.hi), "+v"(P.cp), "+v"(P.up));
         bf16_t* dpl = dp_lds + (t & 1) * PBUF;
+        f32x4 dha;
+        if constexpr (DH == 2) {
+            dha = zero4;
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) dha += P.up[dd] * *reinterpret_cast<const f32x4*>(wo_lds + dd * H + u0);
+        } else dha = P.up;
+        const f32x4 cprev = t > 0 ? P.cp : zero4;
         f32x4 dpre[4];
         {
-            const f32x4 dh = P.dha + dh_rec;
+            const f32x4 dh = dha * vmask + dh_rec;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float s_i = (float)P.lo[r], s_f = (float)P.lo[4 + r], s_g = (float)P.hi[r], s_o = (float)P.hi[4 + r];
                 const float tc = tanh_fast(c_cur[r]);
                 const float d_o = dh[r] * tc;
                 const float dcr = dc[r] + dh[r] * s_o * (1.0f - tc * tc);
-                const float d_i = dcr * s_g, d_g = dcr * s_i, d_f = dcr * P.cp[r];
+                const float d_i = dcr * s_g, d_g = dcr * s_i, d_f = dcr * cprev[r];
                 dc[r] = dcr * s_f;
                 dpre[0][r] = d_i * s_i * (1.0f - s_i);
                 dpre[1][r] = d_f * s_f * (1.0f - s_f);
@@ -96,13 +108,14 @@ __global__ void __launch_bounds__(4 * H) lstm_bwd_bf16_kernel(LstmBwdArgsB a) {
                 dpre[3][r] = d_o * s_o * (1.0f - s_o);
             }
         }
-        c_cur = P.cp;                                      // c_{t-1} is the cell state of the next (earlier) step
+        c_cur = cprev;                                     // c_{t-1} is the cell state of the next (earlier) step
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const bf16x4 pb = cvt_bf16x4(dpre[g]);
             *reinterpret_cast<bf16x4*>(dpl + (g * 16 + j) * RS + u0) = pb;
             tsum[g] += dpre[g];
-            if (bvalid) *reinterpret_cast<bf16x4*>(a.dpre_seq + ((size_t)b * T + t) * 4 * H + g * H + u0) = pb;
+            // dpre_seq is allocated for whole tiles (ceil(B/16)*16 rows): the store is unconditional, rows >= B are padding
+            *reinterpret_cast<bf16x4*>(a.dpre_seq + ((size_t)b * T + t) * 4 * H + g * H + u0) = pb;
         }
         fetch(P, t - 3);                                   // refill the slot: 3 steps of latency cover
         __syncthreads();
@@ -121,11 +134,17 @@ __global__ void __launch_bounds__(4 * H) lstm_bwd_bf16_kernel(LstmBwdArgsB a) {
     __syncthreads();                                       // wo_lds visible
     Prefetch P0, P1, P2;
     c_cur = *reinterpret_cast<const f32x4*>(svc + (size_t)(T - 1) * NW * 64 * 4);
-    fetch(P0, T - 1); fetch(P1, T - 2); fetch(P2, T - 3);
-    for (int t = T - 1; t >= 0; t -= 3) {
+    if (a.dh_last) dh_rec = vmask * *reinterpret_cast<const f32x4*>(a.dh_last + (size_t)bc * H + u0);   // gradient on h_{T-1}
+    int t = T - 1;
+    for (int k = T % 3; k > 0; --k, --t) { fetch(P0, t); step(P0, t); }     // peel so that the main loop runs whole triples
+    fetch(P0, t); fetch(P1, t - 1); fetch(P2, t - 2);
+    // Drain once here: the waits inside the loop are static, so anything still in flight from the prologue (weights,
+    // peeled steps, these first fetches) would otherwise force a vmcnt(0) into every iteration.
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0) only
+    for (; t >= 2; t -= 3) {
         step(P0, t);
-        if (t - 1 >= 0) step(P1, t - 1);
-        if (t - 2 >= 0) step(P2, t - 2);
+        step(P1, t - 1);
+        step(P2, t - 2);
     }
     if (bvalid && a.dpre_tsum) {
 #pragma unroll
@@ -208,7 +227,9 @@ template <int H>
 int launch_h(const LstmBwdArgsB& a, hipStream_t s) {
     const int tiles = ceil_div(a.B, 16);
     const size_t lds = sizeof(bf16_t) * 2 * 4 * 16 * lds_row_stride(H) + sizeof(float) * (a.dy ? a.Dy * H : 0);
-    hipLaunchKernelGGL(lstm_bwd_bf16_kernel<H>, dim3(tiles), dim3(4 * H), lds, s, a);
+    void (*kern)(LstmBwdArgsB) = a.dy ? (a.Dy == 4 ? lstm_bwd_bf16_kernel<H, 2> : lstm_bwd_bf16_kernel<H, 3>)
+                                 : a.dh_seq ? lstm_bwd_bf16_kernel<H, 1> : lstm_bwd_bf16_kernel<H, 0>;
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(4 * H), lds, s, a);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }

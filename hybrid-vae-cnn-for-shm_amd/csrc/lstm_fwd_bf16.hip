@@ -16,7 +16,10 @@ namespace shm {
 namespace {
 
 // XK: k-steps (of 32) of the input operand.  XF32: dynamic input is fp32 [B,T,In] with In <= 32 (encoder layer 0).
-template <int H, int XK, bool XF32, bool DROP>
+// CONSTIN: the input is one fp32 vector per window (decoder layer 0).  SAVE: keep gates / cell state for BPTT.
+// The time loop is branch-free (clamped loads, unconditional stores into tile-padded buffers, T % 3 steps peeled) so that
+// the compiler emits ONE counted s_waitcnt vmcnt per step instead of draining the queue (see lstm_bwd_bf16.hip).
+template <int H, int XK, bool XF32, bool DROP, bool CONSTIN, bool SAVE>
 __global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
     constexpr int NW = H / 16, NTHR = 64 * NW;
     constexpr int KSH = H / 32;                 // k-steps of the recurrent operand
@@ -31,6 +34,7 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
     const int tid = threadIdx.x, lane = tid & 63, ht = tid >> 6, q = lane >> 4, j = lane & 15;
     const int tile = blockIdx.x, b0 = tile * 16, b = b0 + j;
     const bool bvalid = b < B;
+    const int bc = bvalid ? b : B - 1;                 // clamped row for loads (rows >= B compute on garbage-free clamped data)
     const int u0 = ht * 16 + q * 4;
 
     for (int e = tid; e < 2 * (HBUF + XBUF); e += NTHR) smem_b[e] = (bf16_t)0.f;
@@ -64,48 +68,40 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
     // is static); a slot is committed to LDS one step before it is consumed and refilled 4 steps ahead, so the global-load
     // latency (and the in-order vmcnt queue behind this step's stores) is covered by three full steps.
     struct XSlot { bf16x4 v; float s0, s1; };
+    // XF32 staging: element e of the 16 x In tile -> (window jj, channel kk); two elements per thread cover In <= 16 at H = 32
+    const int xe0 = tid < 16 * In ? tid : 0, xe1 = tid + NTHR < 16 * In ? tid + NTHR : 0;
+    const int xj0 = xe0 / In, xk0 = xe0 - xj0 * In, xj1 = xe1 / In, xk1 = xe1 - xj1 * In;
+    const int xb0 = b0 + xj0 < B ? b0 + xj0 : B - 1, xb1 = b0 + xj1 < B ? b0 + xj1 : B - 1;
     auto x_fetch = [&](XSlot& X, int t) {
-        if (a.in_const || t >= T) return;
+        if constexpr (CONSTIN) return;
+        const int tc = t < T ? t : T - 1;                  // clamp: steps >= T are fetched but never committed
         if constexpr (XF32) {
             const float* xin = reinterpret_cast<const float*>(a.in);
-            X.s0 = X.s1 = 0.f;
-            if (tid < 16 * In) {
-                const int jj = tid / In, kk = tid - jj * In, bb = b0 + jj;
-                if (bb < B) X.s0 = xin[((size_t)bb * T + t) * In + kk];
-            }
-            if (tid + NTHR < 16 * In) {
-                const int e = tid + NTHR, jj = e / In, kk = e - jj * In, bb = b0 + jj;
-                if (bb < B) X.s1 = xin[((size_t)bb * T + t) * In + kk];
-            }
+            X.s0 = xin[((size_t)xb0 * T + tc) * In + xk0];
+            X.s1 = xin[((size_t)xb1 * T + tc) * In + xk1];
         } else {
             const bf16_t* xin = reinterpret_cast<const bf16_t*>(a.in);
-            X.v = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
-            if (bvalid) {
-                const size_t idx = ((size_t)b * T + t) * H + u0;
-                X.v = *reinterpret_cast<const bf16x4*>(xin + idx);
-                if (DROP) {
-                    f32x4 v = cvt_f32x4(X.v);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        v[e] = drop_hash(a.drop_seed, a.drop_stack, (uint32_t)(idx + e)) >= thr ? v[e] * dscale : 0.f;
-                    X.v = cvt_bf16x4(v);
-                }
-            }
+            const size_t idx = ((size_t)bc * T + tc) * H + u0;
+            X.v = *reinterpret_cast<const bf16x4*>(xin + idx);
         }
     };
-    auto x_commit = [&](const XSlot& X, int buf) {
+    auto x_commit = [&](XSlot& X, int t, int buf) {      // t: the step the slot holds
         bf16_t* xl = x_lds + buf * XBUF;
         if constexpr (XF32) {
-            if (tid < 16 * In) {
-                const int jj = tid / In, kk = tid - jj * In;
-                xl[((kk / KQX) * 16 + jj) * RSX + (kk % KQX)] = (bf16_t)X.s0;
-            }
-            if (tid + NTHR < 16 * In) {
-                const int e = tid + NTHR, jj = e / In, kk = e - jj * In;
-                xl[((kk / KQX) * 16 + jj) * RSX + (kk % KQX)] = (bf16_t)X.s1;
-            }
+            asm volatile("" : "+v"(X.s0), "+v"(X.s1));     // pin the use (see lstm_bwd_bf16.hip)
+            if (tid < 16 * In) xl[((xk0 / KQX) * 16 + xj0) * RSX + (xk0 % KQX)] = (bf16_t)X.s0;
+            if (tid + NTHR < 16 * In) xl[((xk1 / KQX) * 16 + xj1) * RSX + (xk1 % KQX)] = (bf16_t)X.s1;
         } else {
-            *reinterpret_cast<bf16x4*>(xl + my_x_off) = X.v;
+            asm volatile("" : "+v"(X.v));
+            bf16x4 v = X.v;
+            if (DROP) {
+                const uint32_t idx = (uint32_t)(((size_t)bc * T + t) * H + u0);
+                f32x4 f = cvt_f32x4(v);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f[e] = drop_hash(a.drop_seed, a.drop_stack, idx + e) >= thr ? f[e] * dscale : 0.f;
+                v = cvt_bf16x4(f);
+            }
+            *reinterpret_cast<bf16x4*>(xl + my_x_off) = v;
         }
     };
 
@@ -130,7 +126,7 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
 
     __syncthreads();
     f32x4 xproj[4];
-    if (a.in_const) {
+    if constexpr (CONSTIN) {
         // decoder layer 0: the same h0 at every step (temporal_vae.py:68) -> project once, keep in registers
         const float* h0 = reinterpret_cast<const float*>(a.in);
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -143,19 +139,19 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
     } else {
         XSlot X;
         x_fetch(X, 0);
-        x_commit(X, 0);
+        x_commit(X, 0, 0);
         __syncthreads();
     }
 
     f32x4 c = {0.f, 0.f, 0.f, 0.f}, h4 = {0.f, 0.f, 0.f, 0.f};
-    bf16_t* svg = a.sv_g ? a.sv_g + (((size_t)tile * T * NW + ht) * 64 + lane) * 16 : nullptr;
-    float* svc = a.sv_c ? a.sv_c + (((size_t)tile * T * NW + ht) * 64 + lane) * 4 : nullptr;
+    bf16_t* svg = SAVE ? a.sv_g + (((size_t)tile * T * NW + ht) * 64 + lane) * 16 : nullptr;
+    float* svc = SAVE ? a.sv_c + (((size_t)tile * T * NW + ht) * 64 + lane) * 4 : nullptr;
 
     // X: slot holding x_{t+1}; committed at the end of the step and refilled with x_{t+4}
     auto step = [&](XSlot& X, int t) {
         const int cur = t & 1;
         f32x4 acc[4];
-        if (a.in_const) {
+        if constexpr (CONSTIN) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) acc[g] = xproj[g];
         } else {
@@ -177,10 +173,13 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
         }
         const bf16x4 hb = cvt_bf16x4(h4);
         *reinterpret_cast<bf16x4*>(h_lds + (cur ^ 1) * HBUF + my_h_off) = hb;
-        if (!a.in_const && t + 1 < T) x_commit(X, cur ^ 1);
-        x_fetch(X, t + 4);
-        if (a.h_seq && bvalid) *reinterpret_cast<bf16x4*>(a.h_seq + ((size_t)b * T + t) * H + u0) = hb;
-        if (svg) {
+        if constexpr (!CONSTIN) {
+            if (t + 1 < T) x_commit(X, t + 1, cur ^ 1);
+            x_fetch(X, t + 4);
+        }
+        // h_seq is allocated for whole tiles (ceil(B/16)*16 rows): unconditional store, rows >= B are padding
+        *reinterpret_cast<bf16x4*>(a.h_seq + ((size_t)b * T + t) * H + u0) = hb;
+        if constexpr (SAVE) {
             bf16_t* p = svg + (size_t)t * NW * 64 * 16;
             bf16x8 lo, hi;
             const bf16x4 bi = cvt_bf16x4(gi), bf = cvt_bf16x4(gf), bg = cvt_bf16x4(gg), bo = cvt_bf16x4(go);
@@ -193,20 +192,29 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
         __syncthreads();
     };
     XSlot X0, X1, X2;
-    x_fetch(X0, 1); x_fetch(X1, 2); x_fetch(X2, 3);
-    for (int t = 0; t < T; t += 3) {
+    int t = 0;
+    for (int k = T % 3; k > 0; --k, ++t) { x_fetch(X0, t + 1); step(X0, t); }   // peel: the main loop runs whole triples
+    x_fetch(X0, t + 1); x_fetch(X1, t + 2); x_fetch(X2, t + 3);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0) once: only steady-state loads cross the back-edge
+    for (; t + 2 < T; t += 3) {
         step(X0, t);
-        if (t + 1 < T) step(X1, t + 1);
-        if (t + 2 < T) step(X2, t + 2);
+        step(X1, t + 1);
+        step(X2, t + 2);
     }
     if (a.h_last && bvalid) *reinterpret_cast<f32x4*>(a.h_last + (size_t)b * H + u0) = h4;
 }
 
-template <int H, int XK, bool XF32>
+template <int H, int XK, bool XF32, bool CONSTIN>
 int launch_x(const LstmFwdArgsB& a, hipStream_t s) {
     const int tiles = ceil_div(a.B, 16);
     const size_t lds = sizeof(bf16_t) * 2 * 4 * 16 * (lds_row_stride(H / 4) + lds_row_stride(XK * 8));
-    auto kern = (a.drop_p > 0.f) ? lstm_fwd_bf16_kernel<H, XK, XF32, true> : lstm_fwd_bf16_kernel<H, XK, XF32, false>;
+    const bool drop = a.drop_p > 0.f && !XF32 && !CONSTIN, save = a.sv_g != nullptr;
+    void (*kern)(LstmFwdArgsB);
+    if constexpr (XF32 || CONSTIN)
+        kern = save ? lstm_fwd_bf16_kernel<H, XK, XF32, false, CONSTIN, true> : lstm_fwd_bf16_kernel<H, XK, XF32, false, CONSTIN, false>;
+    else
+        kern = drop ? (save ? lstm_fwd_bf16_kernel<H, XK, false, true, false, true> : lstm_fwd_bf16_kernel<H, XK, false, true, false, false>)
+                    : (save ? lstm_fwd_bf16_kernel<H, XK, false, false, false, true> : lstm_fwd_bf16_kernel<H, XK, false, false, false, false>);
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(4 * H), lds, s, a);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
@@ -214,12 +222,14 @@ int launch_x(const LstmFwdArgsB& a, hipStream_t s) {
 
 template <int H>
 int launch_h(const LstmFwdArgsB& a, hipStream_t s) {
+    SHM_REQUIRE(a.h_seq != nullptr && (a.sv_g == nullptr) == (a.sv_c == nullptr), SHM_EINVAL, "lstm_fwd_bf16: h_seq / saved buffers");
     if (a.in_f32 && !a.in_const) {
         SHM_REQUIRE(a.In <= 32 && 16 * a.In <= 8 * H, SHM_EINVAL, "lstm_fwd_bf16: fp32 input width %d too wide for H=%d", a.In, H);
-        return launch_x<H, 1, true>(a, s);
+        return launch_x<H, 1, true, false>(a, s);
     }
     SHM_REQUIRE(a.In == H, SHM_EINVAL, "lstm_fwd_bf16: layer input width %d must equal hidden width %d", a.In, H);
-    return launch_x<H, H / 32, false>(a, s);
+    if (a.in_const) return launch_x<H, H / 32, false, true>(a, s);
+    return launch_x<H, H / 32, false, false>(a, s);
 }
 
 }  // namespace
