@@ -235,11 +235,11 @@ extern "C" int shm_vae_plan_create(const shm_vae_config* cfg, int32_t B, int32_t
         p->dyx = take((size_t)B * H); p->dy = take((size_t)B * H); p->dh_last = take((size_t)B * H); p->dh0 = take((size_t)B * H);
         p->recon = take(BT * D); p->d_recon = take(BT * D); p->d_mu = take((size_t)B * Z); p->d_lv = take((size_t)B * Z);
         p->dpre_seq = bf ? take_bytes(2 * tiles * 16 * T * 4 * H) : take(BT * 4 * H);   // bf16: whole tiles (unconditional stores)
-        p->dx_seq = take(BT * H); p->dpre_tsum = take((size_t)B * 4 * H);
+        p->dx_seq = take(bf ? tiles * 16 * T * H : BT * H); p->dpre_tsum = take((size_t)B * 4 * H);
         size_t gp = 0;
         auto upd = [&](int R, int M, int N) { const size_t e = gemm_tn_partial_elems(R, M, N); if (e > gp) gp = e; };
         upd((int)BT, H, D); upd((int)BT, 4 * H, H); upd((int)BT, 4 * H, D); upd(B, 4 * H, H); upd(B, H, Z); upd(B, Z, H);
-        if (bf) { const size_t e = gemm_tn_bf16_partial_elems((int)BT, 4 * H, H); if (e > gp) gp = e; }
+        if (bf) { const size_t e = gemm_tn_bf16_partial_elems((int)(tiles * 16 * T), 4 * H, H); if (e > gp) gp = e; }
         p->gemm_partial_elems = gp;
         p->narrow_scratch = take(narrow_tn_scratch_elems(4 * H, D));
         p->gemm_partial = take(gp > 0 ? gp : 1);
@@ -409,7 +409,8 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
                        uint32_t stack) -> int {
         GemmTnArgsB g;
         memset(&g, 0, sizeof(g));
-        g.A = A; g.lda = lda; g.Bm = Bm; g.ldb = ldb; g.b_f32 = 0; g.C = C; g.R = R; g.M = M; g.N = N; g.shift_T = shift_T;
+        g.A = A; g.lda = lda; g.Bm = Bm; g.ldb = ldb; g.b_f32 = 0; g.C = C; g.R = R; g.M = M; g.N = N;
+        g.shift_T = shift_T; g.shift_rows = 16;              // tile-blocked rows: step t-1 of the same window is 16 rows back
         g.drop_p = dp; g.drop_seed = p->drop_seed; g.drop_stack = stack;
         g.partial = at<float>(ws, p->gemm_partial); g.partial_elems = p->gemm_partial_elems;
         return launch_gemm_tn_bf16(g, s);
@@ -429,8 +430,8 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
     const void* h_top = at<char>(ws, p->dec[L - 1].h_seq);
     {
         KernelTimer kt("dw_gemm.out", s);
-        if ((rc = launch_narrow_tn(h_top, bf ? 1 : 0, H, H, d_recon, D, BT, grads + p->out_w, 0, grads + p->out_b,
-                                   at<float>(ws, p->narrow_scratch), s))) return rc;
+        if ((rc = launch_narrow_tn(h_top, bf ? 1 : 0, H, H, d_recon, D, bf ? ceil_div(B, 16) * 16 * T : BT, grads + p->out_w, 0, grads + p->out_b,
+                                   at<float>(ws, p->narrow_scratch), s, bf ? T : 0, bf ? B : 0))) return rc;
     }
 
     auto run_stack_bwd = [&](LayerInst* st, uint32_t stack, const float* x0, bool is_dec) -> int {
@@ -468,13 +469,14 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
                 }
                 KernelTimer kt(gnm, s);
                 const void* dps = at<char>(ws, p->dpre_seq);
-                if ((r = gemm_bf(dps, G, G, at<char>(ws, st[l].h_seq), H, H, BT, grads + st[l].w_hh, T, 0.f, 0))) return r;
+                const int Rt = ceil_div(B, 16) * 16 * T;      // rows incl. tile padding (padding rows of dpre are exactly zero)
+                if ((r = gemm_bf(dps, G, G, at<char>(ws, st[l].h_seq), H, H, Rt, grads + st[l].w_hh, T, 0.f, 0))) return r;
                 if (l > 0) {
-                    if ((r = gemm_bf(dps, G, G, at<char>(ws, st[l - 1].h_seq), H, H, BT, grads + st[l].w_ih, 0, drop, stack))) return r;
+                    if ((r = gemm_bf(dps, G, G, at<char>(ws, st[l - 1].h_seq), H, H, Rt, grads + st[l].w_ih, 0, drop, stack))) return r;
                 } else if (st[l].in_const) {
                     if ((r = gemm(dpre_tsum, G, G, hb.h0, H, H, B, grads + st[l].w_ih, 0, 0, 0.f, 0))) return r;
                 } else {
-                    if ((r = launch_narrow_tn(dps, 1, G, G, x0, D, BT, grads + st[l].w_ih, 1, nullptr, at<float>(ws, p->narrow_scratch), s))) return r;
+                    if ((r = launch_narrow_tn(dps, 1, G, G, x0, D, Rt, grads + st[l].w_ih, 1, nullptr, at<float>(ws, p->narrow_scratch), s, T, B))) return r;
                 }
                 if ((r = launch_colsum(dpre_tsum, G, B, G, grads + st[l].b_ih, grads + st[l].b_hh, cs, s))) return r;
                 continue;
@@ -566,4 +568,14 @@ extern "C" void shm_dropout_keep_mask(uint64_t drop_seed, int32_t stack, int32_t
     const uint32_t thr = drop_threshold(p);
     const size_t n = (size_t)B * T * H;
     for (size_t i = 0; i < n; ++i) keep[i] = drop_hash(drop_seed, (uint32_t)stack, (uint32_t)i) >= thr ? 1 : 0;
+}
+
+extern "C" void shm_dropout_keep_mask_tiled(uint64_t drop_seed, int32_t stack, int32_t B, int32_t T, int32_t H, float p, uint8_t* keep) {
+    const uint32_t thr = drop_threshold(p);
+    for (int b = 0; b < B; ++b)
+        for (int t = 0; t < T; ++t) {
+            const size_t row = (((size_t)(b >> 4) * T + t) << 4) + (b & 15);          // tile-blocked row of (b, t)
+            for (int k = 0; k < H; ++k)
+                keep[((size_t)b * T + t) * H + k] = drop_hash(drop_seed, (uint32_t)stack, (uint32_t)(row * H + k)) >= thr ? 1 : 0;
+        }
 }

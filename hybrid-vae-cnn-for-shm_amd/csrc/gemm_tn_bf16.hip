@@ -73,8 +73,8 @@ __global__ void __launch_bounds__(256) gemm_tn_bf16_kernel(GemmTnArgsB a, int ti
             if (r < r_end) {
                 if (m0 + c8 < a.M) va = *reinterpret_cast<const bf16x8*>(A + (size_t)r * a.lda + m0 + c8);
                 if (n0 + c8 < a.N) {
-                    if (a.shift_T > 0) {
-                        if (r % a.shift_T != 0) vb = load8<TB>(Bm + (size_t)(r - 1) * a.ldb + n0 + c8);
+                    if (a.shift_T > 0) {     // h_{t-1}: rows are tile-blocked (row = (tile*T + t)*16 + j) -> 16 rows back, zero at t = 0
+                        if ((r / a.shift_rows) % a.shift_T != 0) vb = load8<TB>(Bm + (size_t)(r - a.shift_rows) * a.ldb + n0 + c8);
                     } else {
                         vb = load8<TB>(Bm + (size_t)r * a.ldb + n0 + c8);
                         if (drop) {

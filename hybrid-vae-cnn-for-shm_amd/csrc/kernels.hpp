@@ -64,6 +64,7 @@ int launch_head_grads(int B, int H, int Z, int layer_norm, const HeadBufs& hb, f
                       float* lv_w, float* lv_b, float* ln_w, float* ln_b, hipStream_t s);
 
 // ---- output layer + per-window score; loss --------------------------------------------------------------
+// h_bf16: h_seq is bf16 in tile-blocked row order (row of (b,t) = ((b/16)*T + t)*16 + b%16); else fp32 natural [B,T,H]
 int launch_out_fwd(int B, int T, int D, int H, const void* h_seq, int h_bf16, const float* Wout, const float* bout,
                    const float* x, float* recon, float* score, hipStream_t s);
 int launch_vae_loss(int B, int T, int D, int Z, const float* x, const float* recon, const float* mu, const float* lv,
@@ -89,8 +90,10 @@ int launch_colsum(const float* A, int lda, int R, int N, float* out0, float* out
 size_t colsum_scratch_elems(int R, int N);
 // narrow product out[n][m] = sum_r Bn[r][n] A[r][m] (N <= 16 channels; trans_out writes out[m][n]); A fp32 or bf16
 // bsum_out (optional, natural layout only): [N] column sums of Bn (the bias gradient that goes with the product)
+// tile_T > 0: A's rows are tile-blocked (row r' = (tile*tile_T + t)*16 + j) while Bn is natural [B, tile_T, N]; rows of windows
+// >= tile_B are padding and skipped.
 int launch_narrow_tn(const void* A, int a_bf16, int lda, int M, const float* Bn, int N, int R, float* out, int trans_out,
-                     float* bsum_out, float* scratch, hipStream_t s);
+                     float* bsum_out, float* scratch, hipStream_t s, int tile_T = 0, int tile_B = 0);
 size_t narrow_tn_scratch_elems(int M, int N);
 // out[i] (and out1[i]) = sum_p partial[p*n + i], p < nparts (fixed order)
 int launch_reduce_partials(const float* partial, int nparts, size_t n, float* out0, float* out1, hipStream_t s);
@@ -134,7 +137,8 @@ struct GemmTnArgsB {
     const void* Bm; int ldb;       // [R, N] bf16 or fp32 (b_f32)
     int b_f32;
     float* C;                      // [M, N] dense
-    int R, M, N, shift_T;
+    int R, M, N;
+    int shift_T, shift_rows;       // shift_T > 0: B row r is taken from row r - shift_rows, zero when (r / shift_rows) % shift_T == 0
     float drop_p; uint64_t drop_seed; uint32_t drop_stack;
     float* partial; size_t partial_elems;
 };

@@ -9,6 +9,13 @@
 // only ONE step ahead, and spent ~55 % of its time waiting for those loads (vmcnt retires in order, behind older stores).
 // With dx out, the freed registers hold a 3-step-deep rotating prefetch (loop unrolled x3 so every register index is
 // static and the compiler emits counted vmcnt waits).
+//
+// HBM layouts (bf16 path, chosen so that every per-step access of a workgroup is one contiguous, fully coalesced block):
+//   dpre_seq, h_seq : tile-blocked row-major, row r' = (tile*T + t)*16 + j  (j = window within the 16-window tile);
+//                     dpre_t leaves through the LDS operand image as 16-byte stores (a second ablation showed the
+//                     previous per-lane 8-byte stores into 16 different rows cost 45 % of the kernel);
+//   dx_seq          : MFMA fragment order [tile*T + t][wave][lane][4] — written by dx_gemm, read lane-linearly here;
+//   saved gates / c : fragment order (written by the forward).
 #include "kernels.hpp"
 
 namespace shm {
@@ -65,8 +72,8 @@ __global__ void __launch_bounds__(4 * H) lstm_bwd_bf16_kernel(LstmBwdArgsB a) {
         P.lo = *reinterpret_cast<const bf16x8*>(p);
         P.hi = *reinterpret_cast<const bf16x8*>(p + 8);
         P.cp = *reinterpret_cast<const f32x4*>(svc + (size_t)(tc > 0 ? tc - 1 : 0) * NW * 64 * 4);
-        const size_t row = (size_t)bc * T + tc;
-        if constexpr (DH == 1) P.up = *reinterpret_cast<const f32x4*>(a.dh_seq + row * H + u0);
+        const size_t row = (size_t)bc * T + tc;                        // natural row of dy [B,T,Dy]
+        if constexpr (DH == 1) P.up = *reinterpret_cast<const f32x4*>(a.dh_seq + ((((size_t)tile * T + tc) * NW + ht) * 64 + lane) * 4);
         else if constexpr (DH == 2) P.up = *reinterpret_cast<const f32x4*>(a.dy + row * 4);       // Dy == 4 exactly
         else if constexpr (DH == 3) {
             f32x4 d = zero4;
@@ -114,11 +121,18 @@ __global__ void __launch_bounds__(4 * H) lstm_bwd_bf16_kernel(LstmBwdArgsB a) {
             const bf16x4 pb = cvt_bf16x4(dpre[g]);
             *reinterpret_cast<bf16x4*>(dpl + (g * 16 + j) * RS + u0) = pb;
             tsum[g] += dpre[g];
-            // dpre_seq is allocated for whole tiles (ceil(B/16)*16 rows): the store is unconditional, rows >= B are padding
-            *reinterpret_cast<bf16x4*>(a.dpre_seq + ((size_t)b * T + t) * 4 * H + g * H + u0) = pb;
         }
         fetch(P, t - 3);                                   // refill the slot: 3 steps of latency cover
         __syncthreads();
+        // dpre_t -> HBM out of the now complete image: 2 x 16 B per thread, the 16 x 4H block is contiguous in dpre_seq
+        {
+            bf16_t* dst = a.dpre_seq + ((size_t)tile * T + t) * 16 * 4 * H;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int c = tid + i * NTHR, jj = c / (4 * H / 8), c8 = (c - jj * (4 * H / 8)) * 8, g = c8 / H, u = c8 - g * H;
+                *reinterpret_cast<bf16x8*>(dst + (size_t)c * 8) = *reinterpret_cast<const bf16x8*>(dpl + (g * 16 + jj) * RS + u);
+            }
+        }
         const bf16_t* brow = dpl + (q * 16 + j) * RS;
         f32x4 acc0 = zero4, acc1 = zero4;
 #pragma unroll
@@ -172,7 +186,7 @@ __global__ void __launch_bounds__(4 * H) dx_gemm_bf16_kernel(const bf16_t* __res
     }
     const uint32_t thr = drop_threshold(drop_p);
     const float dscale = DROP ? 1.0f / (1.0f - drop_p) : 1.0f;
-    const int n_tiles = (R + 15) / 16;
+    const int n_tiles = R / 16;                      // R = ceil(B/16)*16*T rows in tile-blocked order: row tile tl = tile*T + t
     const int t0 = blockIdx.x * tiles_per_wg, t1 = min(n_tiles, t0 + tiles_per_wg);
     // staging: a 16-row tile is 16 x 4H bf16 = 16*4H/8 chunks of 16 B; chunk c of row jj -> image slot (gate, jj, unit)
     constexpr int CHUNKS = 16 * 4 * H / 8, CPT = CHUNKS / NTHR;          // = 2 chunks per thread (any H)
@@ -209,15 +223,12 @@ __global__ void __launch_bounds__(4 * H) dx_gemm_bf16_kernel(const bf16_t* __res
             acc1 = mfma_bf16_16x16x32(w[s + 1], bv1, acc1);
         }
         f32x4 d = acc0 + acc1;
-        const int r = tl * 16 + j;
-        if (r < R) {
-            const size_t base = (size_t)r * H + ht * 16 + q * 4;
-            if (DROP) {
+        if (DROP) {                                  // same element index as the forward's staging of the layer input
+            const uint32_t base = (uint32_t)(((size_t)tl * 16 + j) * H + ht * 16 + q * 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) d[e] = drop_hash(drop_seed, drop_stack, (uint32_t)(base + e)) >= thr ? d[e] * dscale : 0.f;
-            }
-            *reinterpret_cast<f32x4*>(dx + base) = d;
+            for (int e = 0; e < 4; ++e) d[e] = drop_hash(drop_seed, drop_stack, base + e) >= thr ? d[e] * dscale : 0.f;
         }
+        *reinterpret_cast<f32x4*>(dx + (((size_t)tl * NW + ht) * 64 + lane) * 4) = d;      // fragment order
         if (tl + 1 < t1) store_tile(cur ^ 1);
         __syncthreads();
     }
@@ -236,7 +247,7 @@ int launch_h(const LstmBwdArgsB& a, hipStream_t s) {
 
 template <int H>
 int launch_dx(const LstmBwdArgsB& a, hipStream_t s) {
-    const int R = a.B * a.T, n_tiles = ceil_div(R, 16);
+    const int R = ceil_div(a.B, 16) * 16 * a.T, n_tiles = R / 16;
     const int tiles_per_wg = n_tiles >= 2048 ? 8 : 1;            // 1024 workgroups at the north-star shape
     const int grid = ceil_div(n_tiles, tiles_per_wg);
     if (a.drop_p > 0.f)

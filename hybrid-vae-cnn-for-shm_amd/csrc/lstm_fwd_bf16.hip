@@ -8,7 +8,10 @@
 //     touches no weight memory at all;
 //   * h_t returns to LDS as bf16 in a quarter-major, conflict-free image (common.hpp: lds_row_stride);
 //   * sigmoid/tanh use v_exp_f32 / v_rcp_f32;
-//   * saved state for BPTT: gates as bf16 (32 B/lane/step), c as fp32 (16 B/lane/step), both in fragment order.
+//   * saved state for BPTT: gates as bf16 (32 B/lane/step), c as fp32 (16 B/lane/step), both in fragment order;
+//   * h_seq is tile-blocked row-major (row r' = (tile*T + t)*16 + j, see lstm_bwd_bf16.hip): h_t is copied out of the
+//     completed LDS image one step later as 16-byte fully coalesced stores, and the next layer stages x_t = h^{l-1}_t with
+//     16-byte coalesced loads of the same contiguous 16 x H block.
 #include "kernels.hpp"
 
 namespace shm {
@@ -34,7 +37,6 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
     const int tid = threadIdx.x, lane = tid & 63, ht = tid >> 6, q = lane >> 4, j = lane & 15;
     const int tile = blockIdx.x, b0 = tile * 16, b = b0 + j;
     const bool bvalid = b < B;
-    const int bc = bvalid ? b : B - 1;                 // clamped row for loads (rows >= B compute on garbage-free clamped data)
     const int u0 = ht * 16 + q * 4;
 
     for (int e = tid; e < 2 * (HBUF + XBUF); e += NTHR) smem_b[e] = (bf16_t)0.f;
@@ -67,7 +69,10 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
     // ---- x staging: x_{t+1..t+3} travel in three rotating register slots (the loop below is unrolled x3 so the slot index
     // is static); a slot is committed to LDS one step before it is consumed and refilled 4 steps ahead, so the global-load
     // latency (and the in-order vmcnt queue behind this step's stores) is covered by three full steps.
-    struct XSlot { bf16x4 v; float s0, s1; };
+    struct XSlot { bf16x8 v; float s0, s1; };
+    // bf16 input (layer >= 1): the 16 x H block of step t is contiguous; thread c < 2H moves the 16-byte chunk (row jj, cols c8..c8+7)
+    const int xc = tid < 2 * H ? tid : 0, xjj = xc / (H / 8), xc8 = (xc - xjj * (H / 8)) * 8;
+    const int x_img_off = ((xc8 / KQX) * 16 + xjj) * RSX + (xc8 % KQX);
     // XF32 staging: element e of the 16 x In tile -> (window jj, channel kk); two elements per thread cover In <= 16 at H = 32
     const int xe0 = tid < 16 * In ? tid : 0, xe1 = tid + NTHR < 16 * In ? tid + NTHR : 0;
     const int xj0 = xe0 / In, xk0 = xe0 - xj0 * In, xj1 = xe1 / In, xk1 = xe1 - xj1 * In;
@@ -81,8 +86,7 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
             X.s1 = xin[((size_t)xb1 * T + tc) * In + xk1];
         } else {
             const bf16_t* xin = reinterpret_cast<const bf16_t*>(a.in);
-            const size_t idx = ((size_t)bc * T + tc) * H + u0;
-            X.v = *reinterpret_cast<const bf16x4*>(xin + idx);
+            X.v = *reinterpret_cast<const bf16x8*>(xin + ((size_t)tile * T + tc) * 16 * H + (size_t)xc * 8);
         }
     };
     auto x_commit = [&](XSlot& X, int t, int buf) {      // t: the step the slot holds
@@ -93,15 +97,13 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
             if (tid + NTHR < 16 * In) xl[((xk1 / KQX) * 16 + xj1) * RSX + (xk1 % KQX)] = (bf16_t)X.s1;
         } else {
             asm volatile("" : "+v"(X.v));
-            bf16x4 v = X.v;
-            if (DROP) {
-                const uint32_t idx = (uint32_t)(((size_t)bc * T + t) * H + u0);
-                f32x4 f = cvt_f32x4(v);
+            bf16x8 v = X.v;
+            if (DROP) {     // element index = (tile-blocked row) * H + unit: identical in dx_gemm and the dW_ih GEMM staging
+                const uint32_t idx = (uint32_t)((((size_t)tile * T + t) * 16 + xjj) * H + xc8);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) f[e] = drop_hash(a.drop_seed, a.drop_stack, idx + e) >= thr ? f[e] * dscale : 0.f;
-                v = cvt_bf16x4(f);
+                for (int e = 0; e < 8; ++e) v[e] = drop_hash(a.drop_seed, a.drop_stack, idx + e) >= thr ? (bf16_t)((float)v[e] * dscale) : (bf16_t)0.f;
             }
-            *reinterpret_cast<bf16x4*>(xl + my_x_off) = v;
+            if (tid < 2 * H) *reinterpret_cast<bf16x8*>(xl + x_img_off) = v;
         }
     };
 
@@ -148,8 +150,16 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
     float* svc = SAVE ? a.sv_c + (((size_t)tile * T * NW + ht) * 64 + lane) * 4 : nullptr;
 
     // X: slot holding x_{t+1}; committed at the end of the step and refilled with x_{t+4}
+    // h_{t} image -> h_seq block (tile, t): 16-byte chunks, fully coalesced; called once the image is complete (after the barrier)
+    const int hq = xc8 / KQH, h_img_off = (hq * 16 + xjj) * RSH + (xc8 % KQH);
+    auto h_flush = [&](int t_done, int buf) {
+        if (tid < 2 * H)
+            *reinterpret_cast<bf16x8*>(a.h_seq + ((size_t)tile * T + t_done) * 16 * H + (size_t)xc * 8) =
+                *reinterpret_cast<const bf16x8*>(h_lds + buf * HBUF + h_img_off);
+    };
     auto step = [&](XSlot& X, int t) {
         const int cur = t & 1;
+        if (t > 0) h_flush(t - 1, cur);                    // h_{t-1} sits complete in h_lds[cur]
         f32x4 acc[4];
         if constexpr (CONSTIN) {
 #pragma unroll
@@ -177,8 +187,6 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
             if (t + 1 < T) x_commit(X, t + 1, cur ^ 1);
             x_fetch(X, t + 4);
         }
-        // h_seq is allocated for whole tiles (ceil(B/16)*16 rows): unconditional store, rows >= B are padding
-        *reinterpret_cast<bf16x4*>(a.h_seq + ((size_t)b * T + t) * H + u0) = hb;
         if constexpr (SAVE) {
             bf16_t* p = svg + (size_t)t * NW * 64 * 16;
             bf16x8 lo, hi;
@@ -201,6 +209,7 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
         step(X1, t + 1);
         step(X2, t + 2);
     }
+    h_flush(T - 1, T & 1);                                 // the last image (written into buffer (T-1)&1 ^ 1 = T&1, barrier passed)
     if (a.h_last && bvalid) *reinterpret_cast<f32x4*>(a.h_last + (size_t)b * H + u0) = h4;
 }
 

@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(256) head_grads_kernel(int B, int H, int Z, in
 
 // ------------------------------------------------------------------------------------------------ output layer + score
 constexpr int DMAX = 16;
-template <typename TH>
+template <typename TH, bool TILED>
 __global__ void __launch_bounds__(256) out_fwd_kernel(int T, int D, int H, const TH* __restrict__ h_seq,
                                                       const float* __restrict__ Wout, const float* __restrict__ bout,
                                                       const float* __restrict__ x, float* __restrict__ recon,
@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(256) out_fwd_kernel(int T, int D, int H, const
     const float bias = lane < D ? bout[lane] : 0.f;
     float sq = 0.f;
     for (int t = w; t < T; t += 4) {
-        const TH* h = h_seq + ((size_t)b * T + t) * H;
+        const TH* h = TILED ? h_seq + ((((size_t)(b >> 4) * T + t) << 4) + (b & 15)) * H : h_seq + ((size_t)b * T + t) * H;
         float hv[HMAX / 64];
 #pragma unroll
         for (int i = 0; i < HMAX / 64; ++i) { const int k = lane + 64 * i; hv[i] = k < H ? (float)h[k] : 0.f; }
@@ -352,7 +352,7 @@ template <> struct VecLoad<bf16_t, 8> { static __device__ __forceinline__ void l
 // CPT columns per thread: 8 (one 16/32-byte vector load per row) for <= 4 channels, 2 for up to 16 channels.
 template <typename TA, int NMAX, int CPT>
 __global__ void __launch_bounds__(256) narrow_tn_kernel(const TA* __restrict__ A, int lda, int M, const float* __restrict__ Bn, int N,
-                                                        int R, float* __restrict__ partial, int with_bsum) {
+                                                        int R, float* __restrict__ partial, int with_bsum, int tile_T, int tile_B) {
     extern __shared__ float nred[];                     // [groups][NMAX][M] (+ [groups][NMAX] column sums of Bn)
     const int tpr = M / CPT;                            // threads per row
     const int groups = 256 / tpr;                       // rows in flight per block
@@ -370,12 +370,18 @@ __global__ void __launch_bounds__(256) narrow_tn_kernel(const TA* __restrict__ A
     if (grp < groups) {
 #pragma unroll 2
         for (int r = r0 + grp; r < r1; r += groups) {
+            size_t rb = (size_t)r;                        // row of Bn that pairs with row r of A
+            if (tile_T > 0) {
+                const int blk = r >> 4, tl = blk / tile_T, tt = blk - tl * tile_T, bb = (tl << 4) + (r & 15);
+                if (bb >= tile_B) continue;               // padding window
+                rb = (size_t)bb * tile_T + tt;
+            }
             float av[CPT];
             VecLoad<TA, CPT>::ld(A + (size_t)r * lda + m, av);
 #pragma unroll
             for (int n = 0; n < NMAX; ++n) {
                 if (n < N) {
-                    const float bv = Bn[(size_t)r * N + n];
+                    const float bv = Bn[rb * N + n];
                     bs[n] += bv;
 #pragma unroll
                     for (int c = 0; c < CPT; ++c) acc[n][c] = fmaf(bv, av[c], acc[n][c]);
@@ -490,9 +496,9 @@ int launch_out_fwd(int B, int T, int D, int H, const void* h_seq, int h_bf16, co
                    float* recon, float* score, hipStream_t s) {
     SHM_REQUIRE(D <= DMAX && H <= HMAX, SHM_EINVAL, "out: D=%d (<=%d) H=%d unsupported", D, DMAX, H);
     if (h_bf16)
-        hipLaunchKernelGGL(out_fwd_kernel<bf16_t>, dim3(B), dim3(256), 0, s, T, D, H, (const bf16_t*)h_seq, Wout, bout, x, recon, score);
+        hipLaunchKernelGGL((out_fwd_kernel<bf16_t, true>), dim3(B), dim3(256), 0, s, T, D, H, (const bf16_t*)h_seq, Wout, bout, x, recon, score);
     else
-        hipLaunchKernelGGL(out_fwd_kernel<float>, dim3(B), dim3(256), 0, s, T, D, H, (const float*)h_seq, Wout, bout, x, recon, score);
+        hipLaunchKernelGGL((out_fwd_kernel<float, false>), dim3(B), dim3(256), 0, s, T, D, H, (const float*)h_seq, Wout, bout, x, recon, score);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
@@ -530,7 +536,7 @@ int launch_pack_bwd_f32(const float* W, int H, int M, float* dst, hipStream_t s)
 }
 size_t narrow_tn_scratch_elems(int M, int N) { return (size_t)(NARROW_BLOCKS + 1) * (M * N + N); }
 int launch_narrow_tn(const void* A, int a_bf16, int lda, int M, const float* Bn, int N, int R, float* out, int trans_out,
-                     float* bsum_out, float* scratch, hipStream_t s) {
+                     float* bsum_out, float* scratch, hipStream_t s, int tile_T, int tile_B) {
     const int cpt = N <= 4 ? 8 : 2, nmax = N <= 4 ? 4 : 16;
     SHM_REQUIRE(N >= 1 && N <= 16 && M >= cpt && M <= 512 && M % cpt == 0 && 256 % (M / cpt) == 0 && lda % cpt == 0, SHM_EINVAL,
                 "narrow_tn: unsupported shape M=%d N=%d lda=%d", M, N, lda);
@@ -540,7 +546,7 @@ int launch_narrow_tn(const void* A, int a_bf16, int lda, int M, const float* Bn,
     const int blocks = R < NARROW_BLOCKS * groups * 2 ? ceil_div(R, groups * 2) : NARROW_BLOCKS;
     const int wb = bsum_out ? 1 : 0;
     const size_t stride = (size_t)M * N + (wb ? N : 0);
-#define SHM_NARROW(TA, NM, CP) hipLaunchKernelGGL((narrow_tn_kernel<TA, NM, CP>), dim3(blocks), dim3(256), lds, s, (const TA*)A, lda, M, Bn, N, R, scratch, wb)
+#define SHM_NARROW(TA, NM, CP) hipLaunchKernelGGL((narrow_tn_kernel<TA, NM, CP>), dim3(blocks), dim3(256), lds, s, (const TA*)A, lda, M, Bn, N, R, scratch, wb, tile_T, tile_B)
     if (a_bf16) { if (nmax == 4) SHM_NARROW(bf16_t, 4, 8); else SHM_NARROW(bf16_t, 16, 2); }
     else { if (nmax == 4) SHM_NARROW(float, 4, 8); else SHM_NARROW(float, 16, 2); }
 #undef SHM_NARROW

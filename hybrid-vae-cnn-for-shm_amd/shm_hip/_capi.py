@@ -65,6 +65,7 @@ def _load():
         "shm_profile_begin": (C.c_int, []),
         "shm_profile_end": (C.c_int, [C.c_char_p, C.c_size_t]),
         "shm_dropout_keep_mask": (None, [C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, vp]),
+        "shm_dropout_keep_mask_tiled": (None, [C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch

@@ -147,6 +147,9 @@ int  shm_profile_end(char* json, size_t cap);
 /* Host-side replica of the dropout counter RNG (so tests can rebuild the masks the kernels used).
  * keep[i] = 1 if element (b,t,k) of the layer-0 output of stack `stack` (0 = encoder, 1 = decoder) is kept. */
 void shm_dropout_keep_mask(uint64_t drop_seed, int32_t stack, int32_t B, int32_t T, int32_t H, float p, uint8_t* keep);
+/* Same for SHM_PREC_BF16 plans, whose sequences live in 16-window tile-blocked row order (the RNG is indexed by the
+ * element's position in that layout); keep[] is still written in natural [B,T,H] order. */
+void shm_dropout_keep_mask_tiled(uint64_t drop_seed, int32_t stack, int32_t B, int32_t T, int32_t H, float p, uint8_t* keep);
 
 #ifdef __cplusplus
 }

@@ -104,3 +104,34 @@ def test_bf16_full_size_properties():
     assert torch.equal(r1, r2) and torch.equal(m1, m2)
     assert torch.equal(r1[:100], r3) and torch.equal(m1[:100], m3)
     assert torch.isfinite(r1).all()
+
+
+def test_bf16_train_mode_dropout_matches_oracle_with_same_masks():
+    """bf16 path, inter-layer dropout 0.3: masks rebuilt on the host (tile-blocked RNG indexing) and fed to the fp64 oracle."""
+    import ctypes as C
+    from oracle.vae_oracle import VAEOracle
+    from shm_hip._capi import lib
+    from shm_hip.trainer import VAETrainer
+    g = load_golden("vae_train_mini")
+    cfg = g["cfg"]
+    p0 = split_prefix(g, "p0.")
+    m = build_module(cfg, p0, dropout=0.3).train()
+    tr = VAETrainer(m, lr=1e-3, weight_decay=1e-5, max_norm=2.0)
+    x, eps = g["x0"], g["eps0"]
+    B, T, H = x.shape[0], x.shape[1], cfg["hidden_dim"]
+    seed = 0x77AB12345
+    stats = tr.step(torch.tensor(x).cuda(), 0.37, eps=torch.tensor(eps).cuda(), drop_seed=seed).cpu().numpy()
+    masks = {}
+    for stack, key in ((0, "enc"), (1, "dec")):
+        buf = np.zeros(B * T * H, dtype=np.uint8)
+        lib.shm_dropout_keep_mask_tiled(C.c_uint64(seed), stack, B, T, H, C.c_float(0.3), buf.ctypes.data_as(C.c_void_p))
+        masks[key] = buf.reshape(B, T, H).astype(np.float64)
+        assert 0.6 < masks[key].mean() < 0.8
+    o = VAEOracle(p0, 2, True)
+    o.forward(x, eps, masks, 0.3)
+    losses, grads = o.loss_and_grads(0.37)
+    assert abs(stats[0] - losses["loss"]) < 5e-4 * max(1, losses["loss"])
+    got = dict(zip([k for k, _, _ in tr.engine.layout], tr.engine.split(tr.grads)))
+    rep = {k: float(np.linalg.norm(got[k].cpu().numpy().astype(np.float64) - v) / max(np.linalg.norm(v), 1e-12)) for k, v in grads.items()}
+    print("bf16 dropout grad rel-L2 max", max(rep.values()))
+    assert max(rep.values()) < 2e-2, rep
