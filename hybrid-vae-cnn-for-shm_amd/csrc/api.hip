@@ -197,7 +197,9 @@ extern "C" int shm_vae_plan_create(const shm_vae_config* cfg, int32_t B, int32_t
     auto take_bytes = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     auto take = [&](size_t elems) { return take_bytes(elems * sizeof(float)); };
     const bool bf = cfg->precision == SHM_PREC_BF16;
-    const size_t tiles = (size_t)ceil_div(B, 16);
+    const size_t tiles = (size_t)ceil_div(B, 16);                 // fp32 path: 16-window tiles
+    const size_t qt = (size_t)ceil_div(B, SHM_WPT);               // bf16 path: SHM_WPT-window tiles
+    const size_t Rq = (qt * SHM_WPT * T + 15) / 16 * 16;          // bf16 path: tile-blocked rows, padded to whole MFMA fragments
     const size_t BT = (size_t)B * T;
     for (int l = 0; l < L; ++l) {
         for (int s = 0; s < 2; ++s) {
@@ -206,12 +208,11 @@ extern "C" int shm_vae_plan_create(const shm_vae_config* cfg, int32_t B, int32_t
             if (bf) {
                 li.Wx = take_bytes(2 * fwd_pack_elems_bf16(H, li.In));
                 li.Wh = take_bytes(2 * fwd_pack_elems_bf16(H, H));
-                li.h_seq = take_bytes(2 * tiles * 16 * T * H);            // whole tiles: unconditional stores in the kernel
+                li.h_seq = take_bytes(2 * Rq * H);                        // whole tiles: unconditional stores in the kernel
                 if (training) {
                     li.WhT = take_bytes(2 * bwd_pack_elems_bf16(H, H));
                     if (l > 0) li.WxT = take_bytes(2 * bwd_pack_elems_bf16(H, li.In));
-                    li.saved = take_bytes(2 * tiles * T * 64 * H);      // 4 gates x 16 windows x H units, bf16
-                    li.saved_c = take(tiles * T * 16 * H);              // cell state, fp32
+                    li.saved = take_bytes(16 * qt * T * 4 * H);         // one 16-byte record per lane (4H lanes) and step
                 }
             } else {
                 li.Wx = take(fwd_pack_elems(H, li.In));
@@ -234,12 +235,12 @@ extern "C" int shm_vae_plan_create(const shm_vae_config* cfg, int32_t B, int32_t
         p->dpre_l2h = take((size_t)B * H); p->dmu = take((size_t)B * Z); p->dlv = take((size_t)B * Z);
         p->dyx = take((size_t)B * H); p->dy = take((size_t)B * H); p->dh_last = take((size_t)B * H); p->dh0 = take((size_t)B * H);
         p->recon = take(BT * D); p->d_recon = take(BT * D); p->d_mu = take((size_t)B * Z); p->d_lv = take((size_t)B * Z);
-        p->dpre_seq = bf ? take_bytes(2 * tiles * 16 * T * 4 * H) : take(BT * 4 * H);   // bf16: whole tiles (unconditional stores)
-        p->dx_seq = take(bf ? tiles * 16 * T * H : BT * H); p->dpre_tsum = take((size_t)B * 4 * H);
+        p->dpre_seq = bf ? take_bytes(2 * Rq * 4 * H) : take(BT * 4 * H);   // bf16: whole tiles (unconditional stores)
+        p->dx_seq = take(bf ? Rq * H : BT * H); p->dpre_tsum = take((size_t)B * 4 * H);
         size_t gp = 0;
         auto upd = [&](int R, int M, int N) { const size_t e = gemm_tn_partial_elems(R, M, N); if (e > gp) gp = e; };
         upd((int)BT, H, D); upd((int)BT, 4 * H, H); upd((int)BT, 4 * H, D); upd(B, 4 * H, H); upd(B, H, Z); upd(B, Z, H);
-        if (bf) { const size_t e = gemm_tn_bf16_partial_elems((int)(tiles * 16 * T), 4 * H, H); if (e > gp) gp = e; }
+        if (bf) { const size_t e = gemm_tn_bf16_partial_elems((int)(qt * SHM_WPT * T), 4 * H, H); if (e > gp) gp = e; }
         p->gemm_partial_elems = gp;
         p->narrow_scratch = take(narrow_tn_scratch_elems(4 * H, D));
         p->gemm_partial = take(gp > 0 ? gp : 1);
@@ -325,7 +326,6 @@ extern "C" int shm_vae_forward(shm_vae_plan* p, const float* x, const float* eps
                 a.h_seq = at<bf16_t>(ws, st[l].h_seq);
                 a.h_last = (l == L - 1) ? h_last : nullptr;
                 a.sv_g = save ? at<bf16_t>(ws, st[l].saved) : nullptr;
-                a.sv_c = save ? at<float>(ws, st[l].saved_c) : nullptr;
                 a.B = B; a.T = T; a.In = st[l].In; a.in_const = st[l].in_const ? 1 : 0;
                 a.drop_p = l > 0 ? drop : 0.f; a.drop_seed = drop_seed; a.drop_stack = stack;
                 KernelTimer kt(nm, s);
@@ -410,7 +410,7 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
         GemmTnArgsB g;
         memset(&g, 0, sizeof(g));
         g.A = A; g.lda = lda; g.Bm = Bm; g.ldb = ldb; g.b_f32 = 0; g.C = C; g.R = R; g.M = M; g.N = N;
-        g.shift_T = shift_T; g.shift_rows = 16;              // tile-blocked rows: step t-1 of the same window is 16 rows back
+        g.shift_T = shift_T; g.shift_rows = SHM_WPT;         // tile-blocked rows: step t-1 of the same window is SHM_WPT rows back
         g.drop_p = dp; g.drop_seed = p->drop_seed; g.drop_stack = stack;
         g.partial = at<float>(ws, p->gemm_partial); g.partial_elems = p->gemm_partial_elems;
         return launch_gemm_tn_bf16(g, s);
@@ -430,7 +430,7 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
     const void* h_top = at<char>(ws, p->dec[L - 1].h_seq);
     {
         KernelTimer kt("dw_gemm.out", s);
-        if ((rc = launch_narrow_tn(h_top, bf ? 1 : 0, H, H, d_recon, D, bf ? ceil_div(B, 16) * 16 * T : BT, grads + p->out_w, 0, grads + p->out_b,
+        if ((rc = launch_narrow_tn(h_top, bf ? 1 : 0, H, H, d_recon, D, bf ? ceil_div(B, SHM_WPT) * SHM_WPT * T : BT, grads + p->out_w, 0, grads + p->out_b,
                                    at<float>(ws, p->narrow_scratch), s, bf ? T : 0, bf ? B : 0))) return rc;
     }
 
@@ -442,7 +442,7 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
             if (bf) {
                 LstmBwdArgsB a;
                 memset(&a, 0, sizeof(a));
-                a.sv_g = at<bf16_t>(ws, st[l].saved); a.sv_c = at<float>(ws, st[l].saved_c);
+                a.sv_g = at<bf16_t>(ws, st[l].saved);
                 if (l == L - 1) {
                     if (is_dec) { a.dy = d_recon; a.Wout = prm + p->out_w; a.Dy = D; }
                     else a.dh_last = hb.dh_last;
@@ -469,7 +469,7 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
                 }
                 KernelTimer kt(gnm, s);
                 const void* dps = at<char>(ws, p->dpre_seq);
-                const int Rt = ceil_div(B, 16) * 16 * T;      // rows incl. tile padding (padding rows of dpre are exactly zero)
+                const int Rt = ceil_div(B, SHM_WPT) * SHM_WPT * T;   // rows incl. tile padding (padding rows of dpre are exactly zero)
                 if ((r = gemm_bf(dps, G, G, at<char>(ws, st[l].h_seq), H, H, Rt, grads + st[l].w_hh, T, 0.f, 0))) return r;
                 if (l > 0) {
                     if ((r = gemm_bf(dps, G, G, at<char>(ws, st[l - 1].h_seq), H, H, Rt, grads + st[l].w_ih, 0, drop, stack))) return r;
@@ -574,7 +574,7 @@ extern "C" void shm_dropout_keep_mask_tiled(uint64_t drop_seed, int32_t stack, i
     const uint32_t thr = drop_threshold(p);
     for (int b = 0; b < B; ++b)
         for (int t = 0; t < T; ++t) {
-            const size_t row = (((size_t)(b >> 4) * T + t) << 4) + (b & 15);          // tile-blocked row of (b, t)
+            const size_t row = ((size_t)(b / SHM_WPT) * T + t) * SHM_WPT + (b % SHM_WPT);   // tile-blocked row of (b, t)
             for (int k = 0; k < H; ++k)
                 keep[((size_t)b * T + t) * H + k] = drop_hash(drop_seed, (uint32_t)stack, (uint32_t)(row * H + k)) >= thr ? 1 : 0;
         }

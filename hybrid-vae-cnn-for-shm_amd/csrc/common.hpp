@@ -35,6 +35,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // D[16x16] += A[16x4] * B[4x16], exact f32 (v_mfma_f32_16x16x4_f32).
 // lane l supplies A[row = l&15][k = l>>4] and B[k = l>>4][col = l&15]; holds D[row = 4*(l>>4)+r][col = l&15], r = 0..3.

@@ -99,6 +99,9 @@ size_t narrow_tn_scratch_elems(int M, int N);
 int launch_reduce_partials(const float* partial, int nparts, size_t n, float* out0, float* out1, hipStream_t s);
 
 // ==== bf16 throughput path (fp32 accumulate / cell state / master weights) ===================================
+// Windows per workgroup of the recurrent kernels ("quad tiles", lstm_fwd_bf16.hip).  Sequence buffers of this path are
+// tile-blocked: row r' of (window b, step t) = ((b / SHM_WPT) * T + t) * SHM_WPT + b % SHM_WPT.
+#define SHM_WPT 4
 // Packed forward operand (bf16): Kpad = round_up(K,32), KQ = Kpad/4, KS = KQ/8 k-steps of 32
 //   packed[((ht*KS + s)*4 + g)*64 + lane][e] = W[g*H + ht*16 + (lane&15)][(lane>>4)*KQ + 8*s + e], e = 0..7
 // Packed backward operand (bf16, W^T): KS = H/8 k-steps over K = 4H (lane quarter q <-> gate q)
@@ -110,10 +113,10 @@ struct LstmFwdArgsB {
     const void* in;         // fp32 [B,T,In] (encoder layer 0), fp32 [B,H] (in_const) or bf16 [B,T,H]
     const bf16_t* Wx; const bf16_t* Wh;
     const float* bias;
-    bf16_t* h_seq;          // [B,T,H] bf16
+    bf16_t* h_seq;          // tile-blocked [ceil(B/WPT)*T*WPT, H] bf16
     float* h_last;          // [B,H] fp32 or nullptr
-    bf16_t* sv_g;           // [tile][T][H/16][64][16] gates i,f,g,o (bf16) or nullptr
-    float* sv_c;            // [tile][T][H/16][64][4]  cell state (fp32)
+    bf16_t* sv_g;           // BPTT records [tile][T][H/16][64] x 16 B {i,f|g,o bf16, c_{t-1}, tanh(c_t) fp32} or nullptr
+    float* sv_c;            // unused (kept for ABI stability of the struct)
     int B, T, In, in_const, in_f32;
     float drop_p; uint64_t drop_seed; uint32_t drop_stack;
 };

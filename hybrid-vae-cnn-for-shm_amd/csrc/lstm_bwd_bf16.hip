@@ -11,27 +11,30 @@
 // static and the compiler emits counted vmcnt waits).
 //
 // HBM layouts (bf16 path, chosen so that every per-step access of a workgroup is one contiguous, fully coalesced block):
-//   dpre_seq, h_seq : tile-blocked row-major, row r' = (tile*T + t)*16 + j  (j = window within the 16-window tile);
+//   dpre_seq, h_seq : tile-blocked row-major, row r' = (tile*T + t)*WPT + j  (j = window within the WPT = 4 window tile);
 //                     dpre_t leaves through the LDS operand image as 16-byte stores (a second ablation showed the
 //                     previous per-lane 8-byte stores into 16 different rows cost 45 % of the kernel);
-//   dx_seq          : MFMA fragment order [tile*T + t][wave][lane][4] — written by dx_gemm, read lane-linearly here;
-//   saved gates / c : fragment order (written by the forward).
+//   dx_seq          : MFMA fragment order [r'/16][wave][lane][4] — written by dx_gemm;
+//   saved records   : one 16-byte record per cell and step, fragment order (written by the forward).
+// Quad tiles / one cell per lane: see lstm_fwd_bf16.hip.  After the third ablation (per-CU HBM load bandwidth, ~25 GB/s, was
+// the limiter with 16-window tiles on 32 CUs) a workgroup owns 4 windows: 128 CUs, 20 B of loads per lane and step.
 #include "kernels.hpp"
 
 namespace shm {
 
 namespace {
 
-struct Prefetch {            // operands of one time step, fetched PD = 3 steps ahead
-    bf16x8 lo, hi;           // gates i,f | g,o of the lane's 4 units (bf16)
-    f32x4 cp;                // c_{t-1}
-    f32x4 up;                // DH == 1: dh_seq[b,t,u0..u0+3];  DH == 2: dy[b,t,0..3] (raw, multiplied by W_out at use)
+constexpr int WPT = SHM_WPT;     // windows per workgroup (see lstm_fwd_bf16.hip: quad tiles, one cell per lane)
+
+struct Prefetch {            // operands of one time step of this lane's cell, fetched PD = 3 steps ahead
+    u32x4 rec;               // {i,f | g,o (bf16x2 each), c_{t-1}, tanh(c_t)} written by the forward
+    f32x4 up;                // DH == 1: up[0] = dx of this cell;  DH == 2: dy[b,t,0..3] (raw, multiplied by W_out at use)
 };
 
 // DH: where the gradient on h_t comes from besides the recurrence — 0: nothing (encoder top layer: only h_T, folded into
-// the initial dh_rec), 1: dh_seq from the layer above, 2: output layer with exactly 4 channels, dy[B,T,4] x W_out (top
-// decoder layer at the north-star shape; raw dy is prefetched, the product is formed at use), 3: output layer with any
-// other channel count (dy.W_out evaluated inside the fetch: synchronous fallback for the reference-native shapes).
+// the initial dh_rec), 1: dx of the layer above (fragment order of dx_gemm), 2: output layer with exactly 4 channels,
+// dy[B,T,4] x W_out (top decoder layer at the north-star shape; raw dy is prefetched, the product is formed at use),
+// 3: output layer with any other channel count (dy.W_out evaluated inside the fetch: synchronous fallback).
 // The time loop is branch-free: loads are clamped, never predicated, and T % 3 steps are peeled, so that the compiler can
 // count the loads in flight across the back-edge instead of draining them (s_waitcnt vmcnt(0)) at every loop header.
 template <int H, int DH>
@@ -42,16 +45,19 @@ __global__ void __launch_bounds__(4 * H) lstm_bwd_bf16_kernel(LstmBwdArgsB a) {
     constexpr int PBUF = 4 * 16 * RS;
     extern __shared__ __attribute__((aligned(16))) bf16_t smem_b[];
     bf16_t* dp_lds = smem_b;                                               // [2][PBUF]
-    float* wo_lds = reinterpret_cast<float*>(smem_b + 2 * PBUF);           // [Dy][H]
+    float* scr = reinterpret_cast<float*>(smem_b + 2 * PBUF);              // [NW][64] accumulator re-deal scratch
+    float* wo_lds = scr + NW * 64;                                         // [Dy][H]
 
     const int T = a.T, B = a.B, Dy = a.Dy;
     const int tid = threadIdx.x, lane = tid & 63, ht = tid >> 6, q = lane >> 4, j = lane & 15;
-    const int tile = blockIdx.x, b0 = tile * 16, b = b0 + j;
-    const bool bvalid = b < B;
-    const int bc = bvalid ? b : B - 1;             // clamped row for loads; its contribution is zeroed through vmask
-    const float vmask = bvalid ? 1.f : 0.f;
-    const int u0 = ht * 16 + q * 4;
+    const int tile = blockIdx.x;
+    const int cj = j & 3, cr = j >> 2, cu = ht * 16 + q * 4 + cr;          // my cell: window cj of the tile, unit cu
+    const int cb = tile * WPT + cj;
+    const bool cvalid = cb < B;
+    const int bc = cvalid ? cb : B - 1;            // clamped window for loads; its contribution is zeroed through vmask
+    const float vmask = cvalid ? 1.f : 0.f;
 
+    for (int e = tid; e < 2 * PBUF; e += NTHR) smem_b[e] = (bf16_t)0.f;   // image rows j >= WPT stay zero
     if (DH >= 2)
         for (int e = tid; e < Dy * H; e += NTHR) wo_lds[e] = a.Wout[e];
 
@@ -62,75 +68,71 @@ __global__ void __launch_bounds__(4 * H) lstm_bwd_bf16_kernel(LstmBwdArgsB a) {
         for (int s = 0; s < KS; ++s) whT[s] = p[s * 64];
     }
 
-    const bf16_t* svg = a.sv_g + (((size_t)tile * T * NW + ht) * 64 + lane) * 16;
-    const float* svc = a.sv_c + (((size_t)tile * T * NW + ht) * 64 + lane) * 4;
+    const u32x4* sv = reinterpret_cast<const u32x4*>(a.sv_g) + ((size_t)tile * T * NW + ht) * 64 + lane;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     auto fetch = [&](Prefetch& P, int t) {
         const int tc = t < 0 ? 0 : t;                                  // clamp: steps < 0 are fetched but never used
-        const bf16_t* p = svg + (size_t)tc * NW * 64 * 16;
-        P.lo = *reinterpret_cast<const bf16x8*>(p);
-        P.hi = *reinterpret_cast<const bf16x8*>(p + 8);
-        P.cp = *reinterpret_cast<const f32x4*>(svc + (size_t)(tc > 0 ? tc - 1 : 0) * NW * 64 * 4);
+        P.rec = sv[(size_t)tc * NW * 64];
         const size_t row = (size_t)bc * T + tc;                        // natural row of dy [B,T,Dy]
-        if constexpr (DH == 1) P.up = *reinterpret_cast<const f32x4*>(a.dh_seq + ((((size_t)tile * T + tc) * NW + ht) * 64 + lane) * 4);
-        else if constexpr (DH == 2) P.up = *reinterpret_cast<const f32x4*>(a.dy + row * 4);       // Dy == 4 exactly
+        if constexpr (DH == 1) {
+            // dx_gemm writes 16-row fragments: row r' = (tile*T + t)*WPT + cj sits in fragment r'/16 at lane (q, r'%16), element cr
+            const size_t rp = ((size_t)tile * T + tc) * WPT + cj;
+            P.up = zero4;
+            P.up[0] = a.dh_seq[(((rp >> 4) * NW + ht) * 64 + q * 16 + (rp & 15)) * 4 + cr];
+        } else if constexpr (DH == 2) P.up = *reinterpret_cast<const f32x4*>(a.dy + row * 4);       // Dy == 4 exactly
         else if constexpr (DH == 3) {
-            f32x4 d = zero4;
-            for (int dd = 0; dd < Dy; ++dd) d += a.dy[row * Dy + dd] * *reinterpret_cast<const f32x4*>(wo_lds + dd * H + u0);
-            P.up = d;
+            float d = 0.f;
+            for (int dd = 0; dd < Dy; ++dd) d = fmaf(a.dy[row * Dy + dd], wo_lds[dd * H + cu], d);
+            P.up = zero4; P.up[0] = d;
         } else P.up = zero4;
     };
 
-    f32x4 dc = zero4, dh_rec = zero4, c_cur;
-    f32x4 tsum[4] = {zero4, zero4, zero4, zero4};
+    float dc = 0.f, dh_rec = 0.f;
+    float tsum[4] = {0.f, 0.f, 0.f, 0.f};
+    float* myscr = scr + ht * 64;
 
     // one time step; P holds this step's operands and is refilled with step t-3 once they are consumed
     auto step = [&](Prefetch& P, int t) {
-        // Pin the consumption point of this slot: without it the compiler hoists the bf16->f32 unpacking of the LATER slots
-        // into this step, i.e. touches registers whose loads are still in flight and turns the counted waits into a drain.
-        asm volatile("" : "+v"(P.lo), "+v"(P.hi), "+v"(P.cp), "+v"(P.up));
+        // Pin the consumption point of this slot: without it the compiler hoists the unpacking of the LATER slots into this
+        // step, i.e. touches registers whose loads are still in flight and turns the counted waits into a drain.
+        asm volatile("" : "+v"(P.rec), "+v"(P.up));
         bf16_t* dpl = dp_lds + (t & 1) * PBUF;
-        f32x4 dha;
+        float dha;
         if constexpr (DH == 2) {
-            dha = zero4;
+            dha = 0.f;
 #pragma unroll
-            for (int dd = 0; dd < 4; ++dd) dha += P.up[dd] * *reinterpret_cast<const f32x4*>(wo_lds + dd * H + u0);
-        } else dha = P.up;
-        const f32x4 cprev = t > 0 ? P.cp : zero4;
-        f32x4 dpre[4];
+            for (int dd = 0; dd < 4; ++dd) dha = fmaf(P.up[dd], wo_lds[dd * H + cu], dha);
+        } else dha = P.up[0];
+        const bf16x2 if2 = __builtin_bit_cast(bf16x2, P.rec[0]), go2 = __builtin_bit_cast(bf16x2, P.rec[1]);
+        const float s_i = (float)if2[0], s_f = (float)if2[1], s_g = (float)go2[0], s_o = (float)go2[1];
+        const float c_prev = __uint_as_float(P.rec[2]), tc = __uint_as_float(P.rec[3]);
+        float dpre[4];
         {
-            const f32x4 dh = dha * vmask + dh_rec;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float s_i = (float)P.lo[r], s_f = (float)P.lo[4 + r], s_g = (float)P.hi[r], s_o = (float)P.hi[4 + r];
-                const float tc = tanh_fast(c_cur[r]);
-                const float d_o = dh[r] * tc;
-                const float dcr = dc[r] + dh[r] * s_o * (1.0f - tc * tc);
-                const float d_i = dcr * s_g, d_g = dcr * s_i, d_f = dcr * cprev[r];
-                dc[r] = dcr * s_f;
-                dpre[0][r] = d_i * s_i * (1.0f - s_i);
-                dpre[1][r] = d_f * s_f * (1.0f - s_f);
-                dpre[2][r] = d_g * (1.0f - s_g * s_g);
-                dpre[3][r] = d_o * s_o * (1.0f - s_o);
-            }
+            const float dh = dha * vmask + dh_rec;
+            const float d_o = dh * tc;
+            const float dcr = dc + dh * s_o * (1.0f - tc * tc);
+            const float d_i = dcr * s_g, d_g = dcr * s_i, d_f = dcr * c_prev;
+            dc = dcr * s_f;
+            dpre[0] = d_i * s_i * (1.0f - s_i);
+            dpre[1] = d_f * s_f * (1.0f - s_f);
+            dpre[2] = d_g * (1.0f - s_g * s_g);
+            dpre[3] = d_o * s_o * (1.0f - s_o);
         }
-        c_cur = cprev;                                     // c_{t-1} is the cell state of the next (earlier) step
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const bf16x4 pb = cvt_bf16x4(dpre[g]);
-            *reinterpret_cast<bf16x4*>(dpl + (g * 16 + j) * RS + u0) = pb;
+            dpl[(g * 16 + cj) * RS + cu] = (bf16_t)dpre[g];
             tsum[g] += dpre[g];
         }
         fetch(P, t - 3);                                   // refill the slot: 3 steps of latency cover
         __syncthreads();
-        // dpre_t -> HBM out of the now complete image: 2 x 16 B per thread, the 16 x 4H block is contiguous in dpre_seq
+        // dpre_t -> HBM out of the now complete image: the WPT x 4H block of (tile, t) is contiguous in dpre_seq
         {
-            bf16_t* dst = a.dpre_seq + ((size_t)tile * T + t) * 16 * 4 * H;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int c = tid + i * NTHR, jj = c / (4 * H / 8), c8 = (c - jj * (4 * H / 8)) * 8, g = c8 / H, u = c8 - g * H;
-                *reinterpret_cast<bf16x8*>(dst + (size_t)c * 8) = *reinterpret_cast<const bf16x8*>(dpl + (g * 16 + jj) * RS + u);
+            constexpr int NCH = WPT * 4 * H / 8;           // 16-byte chunks (<= NTHR)
+            if (tid < NCH) {
+                const int jj = tid / (4 * H / 8), c8 = (tid - jj * (4 * H / 8)) * 8, g = c8 / H, u = c8 - g * H;
+                *reinterpret_cast<bf16x8*>(a.dpre_seq + ((size_t)tile * T + t) * WPT * 4 * H + (size_t)tid * 8) =
+                    *reinterpret_cast<const bf16x8*>(dpl + (g * 16 + jj) * RS + u);
             }
         }
         const bf16_t* brow = dpl + (q * 16 + j) * RS;
@@ -142,13 +144,16 @@ __global__ void __launch_bounds__(4 * H) lstm_bwd_bf16_kernel(LstmBwdArgsB a) {
             acc0 = mfma_bf16_16x16x32(whT[s], bv0, acc0);
             acc1 = mfma_bf16_16x16x32(whT[s + 1], bv1, acc1);
         }
-        dh_rec = acc0 + acc1;
+        // accumulator lanes (q, j<4, r) -> cell lanes (same wave: compiler-only barriers)
+        if (j < WPT) *reinterpret_cast<f32x4*>(myscr + (q * 4 + j) * 4) = acc0 + acc1;
+        __builtin_amdgcn_wave_barrier();
+        dh_rec = myscr[(q * 4 + cj) * 4 + cr];
+        __builtin_amdgcn_wave_barrier();
     };
 
-    __syncthreads();                                       // wo_lds visible
+    __syncthreads();                                       // images zeroed, wo_lds visible
     Prefetch P0, P1, P2;
-    c_cur = *reinterpret_cast<const f32x4*>(svc + (size_t)(T - 1) * NW * 64 * 4);
-    if (a.dh_last) dh_rec = vmask * *reinterpret_cast<const f32x4*>(a.dh_last + (size_t)bc * H + u0);   // gradient on h_{T-1}
+    if (a.dh_last) dh_rec = vmask * a.dh_last[(size_t)bc * H + cu];    // gradient on h_{T-1}
     int t = T - 1;
     for (int k = T % 3; k > 0; --k, --t) { fetch(P0, t); step(P0, t); }     // peel so that the main loop runs whole triples
     fetch(P0, t); fetch(P1, t - 1); fetch(P2, t - 2);
@@ -160,9 +165,9 @@ __global__ void __launch_bounds__(4 * H) lstm_bwd_bf16_kernel(LstmBwdArgsB a) {
         step(P1, t - 1);
         step(P2, t - 2);
     }
-    if (bvalid && a.dpre_tsum) {
+    if (cvalid && a.dpre_tsum) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(a.dpre_tsum + (size_t)b * 4 * H + g * H + u0) = tsum[g];
+        for (int g = 0; g < 4; ++g) a.dpre_tsum[(size_t)cb * 4 * H + g * H + cu] = tsum[g];
     }
 }
 
@@ -186,7 +191,7 @@ __global__ void __launch_bounds__(4 * H) dx_gemm_bf16_kernel(const bf16_t* __res
     }
     const uint32_t thr = drop_threshold(drop_p);
     const float dscale = DROP ? 1.0f / (1.0f - drop_p) : 1.0f;
-    const int n_tiles = R / 16;                      // R = ceil(B/16)*16*T rows in tile-blocked order: row tile tl = tile*T + t
+    const int n_tiles = (R + 15) / 16;               // R = ceil(B/WPT)*WPT*T rows in tile-blocked order, 16 rows per MFMA fragment
     const int t0 = blockIdx.x * tiles_per_wg, t1 = min(n_tiles, t0 + tiles_per_wg);
     // staging: a 16-row tile is 16 x 4H bf16 = 16*4H/8 chunks of 16 B; chunk c of row jj -> image slot (gate, jj, unit)
     constexpr int CHUNKS = 16 * 4 * H / 8, CPT = CHUNKS / NTHR;          // = 2 chunks per thread (any H)
@@ -236,8 +241,8 @@ __global__ void __launch_bounds__(4 * H) dx_gemm_bf16_kernel(const bf16_t* __res
 
 template <int H>
 int launch_h(const LstmBwdArgsB& a, hipStream_t s) {
-    const int tiles = ceil_div(a.B, 16);
-    const size_t lds = sizeof(bf16_t) * 2 * 4 * 16 * lds_row_stride(H) + sizeof(float) * (a.dy ? a.Dy * H : 0);
+    const int tiles = ceil_div(a.B, WPT);
+    const size_t lds = sizeof(bf16_t) * 2 * 4 * 16 * lds_row_stride(H) + sizeof(float) * ((H / 16) * 64 + (a.dy ? a.Dy * H : 0));
     void (*kern)(LstmBwdArgsB) = a.dy ? (a.Dy == 4 ? lstm_bwd_bf16_kernel<H, 2> : lstm_bwd_bf16_kernel<H, 3>)
                                  : a.dh_seq ? lstm_bwd_bf16_kernel<H, 1> : lstm_bwd_bf16_kernel<H, 0>;
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(4 * H), lds, s, a);
@@ -247,7 +252,7 @@ int launch_h(const LstmBwdArgsB& a, hipStream_t s) {
 
 template <int H>
 int launch_dx(const LstmBwdArgsB& a, hipStream_t s) {
-    const int R = ceil_div(a.B, 16) * 16 * a.T, n_tiles = R / 16;
+    const int R = ceil_div(a.B, WPT) * WPT * a.T, n_tiles = ceil_div(R, 16);
     const int tiles_per_wg = n_tiles >= 2048 ? 8 : 1;            // 1024 workgroups at the north-star shape
     const int grid = ceil_div(n_tiles, tiles_per_wg);
     if (a.drop_p > 0.f)
@@ -264,7 +269,7 @@ int launch_dx(const LstmBwdArgsB& a, hipStream_t s) {
 
 int launch_lstm_bwd_bf16(int H, const LstmBwdArgsB& a, hipStream_t s) {
     SHM_REQUIRE(a.B > 0 && a.T > 0, SHM_EINVAL, "lstm_bwd_bf16: empty shape");
-    SHM_REQUIRE(a.sv_g && a.sv_c && a.dpre_seq, SHM_ESTATE, "lstm_bwd_bf16: no saved forward state / dpre buffer");
+    SHM_REQUIRE(a.sv_g && a.dpre_seq, SHM_ESTATE, "lstm_bwd_bf16: no saved forward state / dpre buffer");
     SHM_REQUIRE(!a.dy || (a.Wout && a.Dy > 0 && a.Dy <= 64), SHM_EINVAL, "lstm_bwd_bf16: bad output-layer gradient");
     switch (H) {
         case 32: return launch_h<32>(a, s);

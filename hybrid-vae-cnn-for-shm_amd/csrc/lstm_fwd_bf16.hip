@@ -1,43 +1,52 @@
 // lstm_fwd_bf16.hip — persistent LSTM layer forward, bf16 MFMA (v_mfma_f32_16x16x32_bf16), fp32 accumulate and
-// fp32 cell state; gfx950.  Throughput twin of lstm_fwd.hip (same ownership: workgroup = 16 windows, wave w = hidden
-// units [16w,16w+16) x gates i,f,g,o, lane (q,j) = units 16w+4q+r of window j), replacing the nn.LSTM cell loop of
-// reference 4DOF/Scripts/Models/temporal_vae.py:53,69.
+// fp32 cell state; gfx950.  Throughput path behind TemporalVAE.encode/decode (reference
+// 4DOF/Scripts/Models/temporal_vae.py:53,69: the nn.LSTM cell loop).
 //
-// What changes against the fp32 kernel:
-//   * W_hh and W_ih live in REGISTERS for the whole sequence (64 VGPRs per matrix per wave at H=128) — the time loop
-//     touches no weight memory at all;
-//   * h_t returns to LDS as bf16 in a quarter-major, conflict-free image (common.hpp: lds_row_stride);
-//   * sigmoid/tanh use v_exp_f32 / v_rcp_f32;
-//   * saved state for BPTT: gates as bf16 (32 B/lane/step), c as fp32 (16 B/lane/step), both in fragment order;
-//   * h_seq is tile-blocked row-major (row r' = (tile*T + t)*16 + j, see lstm_bwd_bf16.hip): h_t is copied out of the
-//     completed LDS image one step later as 16-byte fully coalesced stores, and the next layer stages x_t = h^{l-1}_t with
-//     16-byte coalesced loads of the same contiguous 16 x H block.
+// Decomposition ("quad tiles"): one workgroup = WPT = 4 windows x all T steps, so B = 512 windows spread over 128 CUs
+// (16-window tiles would use 32).  The recurrence is latency-bound and, per CU, bound by how many HBM bytes a single CU can
+// keep in flight (~25 GB/s), so the design minimises per-CU work and bytes rather than MFMA padding:
+//   * wave w owns hidden units [16w,16w+16) x gates i,f,g,o; W_hh and W_ih fragments live in REGISTERS for the whole
+//     sequence (64 VGPRs per matrix per wave at H = 128); the MFMA computes gates^T[64 x 16] = W . [h|x]^T with the 4 windows
+//     in columns 0..3 of the B operand (columns 4..15 are zero rows of the LDS image);
+//   * the accumulator (lane (q,j) = units 4q..4q+3 of window j, only j < 4 meaningful) is re-dealt through a 1 KiB per-wave
+//     LDS scratch so that EVERY lane owns exactly one cell: lane (q,jj) = unit 4q + (jj>>2) of window jj&3.  The cell update
+//     (5 transcendentals) then costs a quarter of the VALU issue of the 16-window mapping, and c_t is one register;
+//   * saved state for BPTT is ONE 16-byte record per lane per step {i,f | g,o (bf16), c_{t-1}, tanh(c_t) (fp32)} in
+//     fragment order (1 KiB contiguous per wave);
+//   * h_t returns to the LDS operand image as bf16; h_seq is tile-blocked row-major (row r' = (tile*T + t)*4 + j) and is
+//     copied out of the completed image one step later as 16-byte coalesced stores; the next layer stages x_t from the same
+//     contiguous 4 x H block;
+//   * x_{t+1..t+3} are prefetched in three rotating register slots; the time loop is branch-free (clamped loads, T % 3
+//     steps peeled, slot use pinned with an empty asm) so the compiler emits one counted s_waitcnt vmcnt per step.
 #include "kernels.hpp"
 
 namespace shm {
 
 namespace {
 
-// XK: k-steps (of 32) of the input operand.  XF32: dynamic input is fp32 [B,T,In] with In <= 32 (encoder layer 0).
-// CONSTIN: the input is one fp32 vector per window (decoder layer 0).  SAVE: keep gates / cell state for BPTT.
-// The time loop is branch-free (clamped loads, unconditional stores into tile-padded buffers, T % 3 steps peeled) so that
-// the compiler emits ONE counted s_waitcnt vmcnt per step instead of draining the queue (see lstm_bwd_bf16.hip).
+constexpr int WPT = SHM_WPT;     // windows per workgroup
+
+// XK: k-steps (of 32) of the input operand.  XF32: dynamic input is fp32 [B,T,In] with In <= 16 (encoder layer 0).
+// CONSTIN: the input is one fp32 vector per window (decoder layer 0).  SAVE: keep the BPTT records.
 template <int H, int XK, bool XF32, bool DROP, bool CONSTIN, bool SAVE>
 __global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
     constexpr int NW = H / 16, NTHR = 64 * NW;
     constexpr int KSH = H / 32;                 // k-steps of the recurrent operand
     constexpr int KQH = H / 4, RSH = lds_row_stride(KQH);
     constexpr int KQX = XK * 8, RSX = lds_row_stride(KQX);
-    constexpr int HBUF = 4 * 16 * RSH, XBUF = 4 * 16 * RSX;       // elements per buffer
+    constexpr int HBUF = 4 * 16 * RSH, XBUF = 4 * 16 * RSX;       // bf16 elements per operand image
     extern __shared__ __attribute__((aligned(16))) bf16_t smem_b[];
     bf16_t* h_lds = smem_b;                     // [2][HBUF]
     bf16_t* x_lds = smem_b + 2 * HBUF;          // [2][XBUF]
+    float* scr = reinterpret_cast<float*>(smem_b + 2 * (HBUF + XBUF));   // [NW][4 gates][64] accumulator re-deal scratch
 
     const int In = a.In, T = a.T, B = a.B;
     const int tid = threadIdx.x, lane = tid & 63, ht = tid >> 6, q = lane >> 4, j = lane & 15;
-    const int tile = blockIdx.x, b0 = tile * 16, b = b0 + j;
-    const bool bvalid = b < B;
-    const int u0 = ht * 16 + q * 4;
+    const int tile = blockIdx.x;
+    // cell owned by this lane after the re-deal
+    const int cj = j & 3, cr = j >> 2, cu = ht * 16 + q * 4 + cr;      // window within the tile, unit
+    const int cb = tile * WPT + cj;
+    const bool cvalid = cb < B;
 
     for (int e = tid; e < 2 * (HBUF + XBUF); e += NTHR) smem_b[e] = (bf16_t)0.f;
 
@@ -57,53 +66,49 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
     }
     f32x4 bias4[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) bias4[g] = *reinterpret_cast<const f32x4*>(a.bias + g * H + u0);
+    for (int g = 0; g < 4; ++g) bias4[g] = *reinterpret_cast<const f32x4*>(a.bias + g * H + ht * 16 + q * 4);
 
     const uint32_t thr = drop_threshold(a.drop_p);
     const float dscale = DROP ? 1.0f / (1.0f - a.drop_p) : 1.0f;
 
-    // my slot in the operand images: (window j, units u0..u0+3)
-    const int my_h_off = ((u0 / KQH) * 16 + j) * RSH + (u0 % KQH);
-    const int my_x_off = ((u0 / KQX) * 16 + j) * RSX + (u0 % KQX);      // only meaningful when In == H
+    // operand-image slot of my cell (window cj, unit cu)
+    const int my_h_off = ((cu / KQH) * 16 + cj) * RSH + (cu % KQH);
+    const int my_x_off = ((cu / KQX) * 16 + cj) * RSX + (cu % KQX);      // CONSTIN staging (In == H)
 
-    // ---- x staging: x_{t+1..t+3} travel in three rotating register slots (the loop below is unrolled x3 so the slot index
-    // is static); a slot is committed to LDS one step before it is consumed and refilled 4 steps ahead, so the global-load
-    // latency (and the in-order vmcnt queue behind this step's stores) is covered by three full steps.
-    struct XSlot { bf16x8 v; float s0, s1; };
-    // bf16 input (layer >= 1): the 16 x H block of step t is contiguous; thread c < 2H moves the 16-byte chunk (row jj, cols c8..c8+7)
-    const int xc = tid < 2 * H ? tid : 0, xjj = xc / (H / 8), xc8 = (xc - xjj * (H / 8)) * 8;
+    // ---- block copies between HBM and the images: the WPT x H block of a step is contiguous; thread c < WPT*H/8 moves the
+    // 16-byte chunk (row jj, cols c8..c8+7)
+    constexpr int NCH = WPT * H / 8;
+    const int xc = tid < NCH ? tid : 0, xjj = xc / (H / 8), xc8 = (xc - xjj * (H / 8)) * 8;
     const int x_img_off = ((xc8 / KQX) * 16 + xjj) * RSX + (xc8 % KQX);
-    // XF32 staging: element e of the 16 x In tile -> (window jj, channel kk); two elements per thread cover In <= 16 at H = 32
-    const int xe0 = tid < 16 * In ? tid : 0, xe1 = tid + NTHR < 16 * In ? tid + NTHR : 0;
-    const int xj0 = xe0 / In, xk0 = xe0 - xj0 * In, xj1 = xe1 / In, xk1 = xe1 - xj1 * In;
-    const int xb0 = b0 + xj0 < B ? b0 + xj0 : B - 1, xb1 = b0 + xj1 < B ? b0 + xj1 : B - 1;
+    const int h_img_off = ((xc8 / KQH) * 16 + xjj) * RSH + (xc8 % KQH);
+
+    struct XSlot { bf16x8 v; float s0; };
+    // XF32 staging: element e < WPT*In of the tile -> (window jj, channel kk); In <= 16 so one element per thread suffices
+    const int xe = tid < WPT * In ? tid : 0, xj0 = xe / In, xk0 = xe - xj0 * In;
+    const int xb0 = tile * WPT + xj0 < B ? tile * WPT + xj0 : B - 1;
     auto x_fetch = [&](XSlot& X, int t) {
         if constexpr (CONSTIN) return;
         const int tc = t < T ? t : T - 1;                  // clamp: steps >= T are fetched but never committed
         if constexpr (XF32) {
-            const float* xin = reinterpret_cast<const float*>(a.in);
-            X.s0 = xin[((size_t)xb0 * T + tc) * In + xk0];
-            X.s1 = xin[((size_t)xb1 * T + tc) * In + xk1];
+            X.s0 = reinterpret_cast<const float*>(a.in)[((size_t)xb0 * T + tc) * In + xk0];
         } else {
-            const bf16_t* xin = reinterpret_cast<const bf16_t*>(a.in);
-            X.v = *reinterpret_cast<const bf16x8*>(xin + ((size_t)tile * T + tc) * 16 * H + (size_t)xc * 8);
+            X.v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(a.in) + ((size_t)tile * T + tc) * WPT * H + (size_t)xc * 8);
         }
     };
     auto x_commit = [&](XSlot& X, int t, int buf) {      // t: the step the slot holds
         bf16_t* xl = x_lds + buf * XBUF;
         if constexpr (XF32) {
-            asm volatile("" : "+v"(X.s0), "+v"(X.s1));     // pin the use (see lstm_bwd_bf16.hip)
-            if (tid < 16 * In) xl[((xk0 / KQX) * 16 + xj0) * RSX + (xk0 % KQX)] = (bf16_t)X.s0;
-            if (tid + NTHR < 16 * In) xl[((xk1 / KQX) * 16 + xj1) * RSX + (xk1 % KQX)] = (bf16_t)X.s1;
+            asm volatile("" : "+v"(X.s0));                 // pin the use (see lstm_bwd_bf16.hip)
+            if (tid < WPT * In) xl[((xk0 / KQX) * 16 + xj0) * RSX + (xk0 % KQX)] = (bf16_t)X.s0;
         } else {
             asm volatile("" : "+v"(X.v));
             bf16x8 v = X.v;
             if (DROP) {     // element index = (tile-blocked row) * H + unit: identical in dx_gemm and the dW_ih GEMM staging
-                const uint32_t idx = (uint32_t)((((size_t)tile * T + t) * 16 + xjj) * H + xc8);
+                const uint32_t idx = (uint32_t)((((size_t)tile * T + t) * WPT + xjj) * H + xc8);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = drop_hash(a.drop_seed, a.drop_stack, idx + e) >= thr ? (bf16_t)((float)v[e] * dscale) : (bf16_t)0.f;
             }
-            if (tid < 2 * H) *reinterpret_cast<bf16x8*>(xl + x_img_off) = v;
+            if (tid < NCH) *reinterpret_cast<bf16x8*>(xl + x_img_off) = v;
         }
     };
 
@@ -125,15 +130,27 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
             for (int g = 0; g < 4; ++g) acc[g] = mfma_bf16_16x16x32(wx[g][s], bv, acc[g]);
         }
     };
+    // accumulator lanes (q, j<4, r=0..3) -> cell lanes (q, jj): one float per gate.  Same wave on both sides, so a wave
+    // barrier (compiler ordering only) is enough between the LDS writes and reads.
+    float* myscr = scr + ht * 256;
+    auto redeal = [&](const f32x4 (&acc)[4], float (&gate)[4]) {
+        if (j < WPT) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(myscr + g * 64 + (q * 4 + j) * 4) = acc[g];
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gate[g] = myscr[g * 64 + (q * 4 + cj) * 4 + cr];
+        __builtin_amdgcn_wave_barrier();
+    };
 
     __syncthreads();
     f32x4 xproj[4];
     if constexpr (CONSTIN) {
         // decoder layer 0: the same h0 at every step (temporal_vae.py:68) -> project once, keep in registers
         const float* h0 = reinterpret_cast<const float*>(a.in);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (bvalid) v = *reinterpret_cast<const f32x4*>(h0 + (size_t)b * H + u0);
-        *reinterpret_cast<bf16x4*>(x_lds + my_x_off) = cvt_bf16x4(v);
+        const float v = cvalid ? h0[(size_t)cb * H + cu] : 0.f;
+        x_lds[my_x_off] = (bf16_t)v;
         __syncthreads();
 #pragma unroll
         for (int g = 0; g < 4; ++g) xproj[g] = bias4[g];
@@ -145,18 +162,16 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
         __syncthreads();
     }
 
-    f32x4 c = {0.f, 0.f, 0.f, 0.f}, h4 = {0.f, 0.f, 0.f, 0.f};
-    bf16_t* svg = SAVE ? a.sv_g + (((size_t)tile * T * NW + ht) * 64 + lane) * 16 : nullptr;
-    float* svc = SAVE ? a.sv_c + (((size_t)tile * T * NW + ht) * 64 + lane) * 4 : nullptr;
+    float c = 0.f, h = 0.f;
+    u32x4* sv = SAVE ? reinterpret_cast<u32x4*>(a.sv_g) + ((size_t)tile * T * NW + ht) * 64 + lane : nullptr;
 
-    // X: slot holding x_{t+1}; committed at the end of the step and refilled with x_{t+4}
     // h_{t} image -> h_seq block (tile, t): 16-byte chunks, fully coalesced; called once the image is complete (after the barrier)
-    const int hq = xc8 / KQH, h_img_off = (hq * 16 + xjj) * RSH + (xc8 % KQH);
     auto h_flush = [&](int t_done, int buf) {
-        if (tid < 2 * H)
-            *reinterpret_cast<bf16x8*>(a.h_seq + ((size_t)tile * T + t_done) * 16 * H + (size_t)xc * 8) =
+        if (tid < NCH)
+            *reinterpret_cast<bf16x8*>(a.h_seq + ((size_t)tile * T + t_done) * WPT * H + (size_t)xc * 8) =
                 *reinterpret_cast<const bf16x8*>(h_lds + buf * HBUF + h_img_off);
     };
+    // X: slot holding x_{t+1}; committed at the end of the step and refilled with x_{t+4}
     auto step = [&](XSlot& X, int t) {
         const int cur = t & 1;
         if (t > 0) h_flush(t - 1, cur);                    // h_{t-1} sits complete in h_lds[cur]
@@ -171,31 +186,26 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
         }
         mma_h(acc, h_lds + cur * HBUF);
 
-        f32x4 gi, gf, gg, go;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            gi[r] = sigmoid_fast(acc[0][r]);
-            gf[r] = sigmoid_fast(acc[1][r]);
-            gg[r] = tanh_fast(acc[2][r]);
-            go[r] = sigmoid_fast(acc[3][r]);
-            c[r] = gf[r] * c[r] + gi[r] * gg[r];
-            h4[r] = go[r] * tanh_fast(c[r]);
-        }
-        const bf16x4 hb = cvt_bf16x4(h4);
-        *reinterpret_cast<bf16x4*>(h_lds + (cur ^ 1) * HBUF + my_h_off) = hb;
+        float gate[4];
+        redeal(acc, gate);
+        const float gi = sigmoid_fast(gate[0]), gf = sigmoid_fast(gate[1]), gg = tanh_fast(gate[2]), go = sigmoid_fast(gate[3]);
+        const float c_prev = c;
+        c = gf * c + gi * gg;
+        const float tc = tanh_fast(c);
+        h = go * tc;
+        h_lds[(cur ^ 1) * HBUF + my_h_off] = (bf16_t)h;
         if constexpr (!CONSTIN) {
             if (t + 1 < T) x_commit(X, t + 1, cur ^ 1);
             x_fetch(X, t + 4);
         }
         if constexpr (SAVE) {
-            bf16_t* p = svg + (size_t)t * NW * 64 * 16;
-            bf16x8 lo, hi;
-            const bf16x4 bi = cvt_bf16x4(gi), bf = cvt_bf16x4(gf), bg = cvt_bf16x4(gg), bo = cvt_bf16x4(go);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { lo[r] = bi[r]; lo[4 + r] = bf[r]; hi[r] = bg[r]; hi[4 + r] = bo[r]; }
-            *reinterpret_cast<bf16x8*>(p) = lo;
-            *reinterpret_cast<bf16x8*>(p + 8) = hi;
-            *reinterpret_cast<f32x4*>(svc + (size_t)t * NW * 64 * 4) = c;
+            f32x2 a0 = {gi, gf}, a1 = {gg, go};
+            u32x4 rec;
+            rec[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(a0, bf16x2));
+            rec[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(a1, bf16x2));
+            rec[2] = __float_as_uint(c_prev);
+            rec[3] = __float_as_uint(tc);
+            sv[(size_t)t * NW * 64] = rec;
         }
         __syncthreads();
     };
@@ -209,14 +219,14 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
         step(X1, t + 1);
         step(X2, t + 2);
     }
-    h_flush(T - 1, T & 1);                                 // the last image (written into buffer (T-1)&1 ^ 1 = T&1, barrier passed)
-    if (a.h_last && bvalid) *reinterpret_cast<f32x4*>(a.h_last + (size_t)b * H + u0) = h4;
+    h_flush(T - 1, T & 1);                                 // the last image (buffer T&1; its barrier has passed)
+    if (a.h_last && cvalid) a.h_last[(size_t)cb * H + cu] = h;
 }
 
 template <int H, int XK, bool XF32, bool CONSTIN>
 int launch_x(const LstmFwdArgsB& a, hipStream_t s) {
-    const int tiles = ceil_div(a.B, 16);
-    const size_t lds = sizeof(bf16_t) * 2 * 4 * 16 * (lds_row_stride(H / 4) + lds_row_stride(XK * 8));
+    const int tiles = ceil_div(a.B, WPT);
+    const size_t lds = sizeof(bf16_t) * 2 * 4 * 16 * (lds_row_stride(H / 4) + lds_row_stride(XK * 8)) + sizeof(float) * (H / 16) * 256;
     const bool drop = a.drop_p > 0.f && !XF32 && !CONSTIN, save = a.sv_g != nullptr;
     void (*kern)(LstmFwdArgsB);
     if constexpr (XF32 || CONSTIN)
@@ -231,9 +241,9 @@ int launch_x(const LstmFwdArgsB& a, hipStream_t s) {
 
 template <int H>
 int launch_h(const LstmFwdArgsB& a, hipStream_t s) {
-    SHM_REQUIRE(a.h_seq != nullptr && (a.sv_g == nullptr) == (a.sv_c == nullptr), SHM_EINVAL, "lstm_fwd_bf16: h_seq / saved buffers");
+    SHM_REQUIRE(a.h_seq != nullptr, SHM_EINVAL, "lstm_fwd_bf16: h_seq is NULL");
     if (a.in_f32 && !a.in_const) {
-        SHM_REQUIRE(a.In <= 32 && 16 * a.In <= 8 * H, SHM_EINVAL, "lstm_fwd_bf16: fp32 input width %d too wide for H=%d", a.In, H);
+        SHM_REQUIRE(a.In <= 16, SHM_EINVAL, "lstm_fwd_bf16: fp32 input width %d too wide (<= 16)", a.In);
         return launch_x<H, 1, true, false>(a, s);
     }
     SHM_REQUIRE(a.In == H, SHM_EINVAL, "lstm_fwd_bf16: layer input width %d must equal hidden width %d", a.In, H);

@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(256) out_fwd_kernel(int T, int D, int H, const
     const float bias = lane < D ? bout[lane] : 0.f;
     float sq = 0.f;
     for (int t = w; t < T; t += 4) {
-        const TH* h = TILED ? h_seq + ((((size_t)(b >> 4) * T + t) << 4) + (b & 15)) * H : h_seq + ((size_t)b * T + t) * H;
+        const TH* h = TILED ? h_seq + (((size_t)(b / SHM_WPT) * T + t) * SHM_WPT + (b % SHM_WPT)) * H : h_seq + ((size_t)b * T + t) * H;
         float hv[HMAX / 64];
 #pragma unroll
         for (int i = 0; i < HMAX / 64; ++i) { const int k = lane + 64 * i; hv[i] = k < H ? (float)h[k] : 0.f; }
@@ -372,7 +372,7 @@ __global__ void __launch_bounds__(256) narrow_tn_kernel(const TA* __restrict__ A
         for (int r = r0 + grp; r < r1; r += groups) {
             size_t rb = (size_t)r;                        // row of Bn that pairs with row r of A
             if (tile_T > 0) {
-                const int blk = r >> 4, tl = blk / tile_T, tt = blk - tl * tile_T, bb = (tl << 4) + (r & 15);
+                const int blk = r / SHM_WPT, tl = blk / tile_T, tt = blk - tl * tile_T, bb = tl * SHM_WPT + (r - blk * SHM_WPT);
                 if (bb >= tile_B) continue;               // padding window
                 rb = (size_t)bb * tile_T + tt;
             }
