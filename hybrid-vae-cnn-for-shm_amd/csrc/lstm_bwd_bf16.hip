@@ -104,8 +104,10 @@ __global__ void __launch_bounds__(4 * H) lstm_bwd_bf16_kernel(LstmBwdArgsB a) {
 #pragma unroll
             for (int dd = 0; dd < 4; ++dd) dha = fmaf(P.up[dd], wo_lds[dd * H + cu], dha);
         } else dha = P.up[0];
-        const bf16x2 if2 = __builtin_bit_cast(bf16x2, P.rec[0]), go2 = __builtin_bit_cast(bf16x2, P.rec[1]);
-        const float s_i = (float)if2[0], s_f = (float)if2[1], s_g = (float)go2[0], s_o = (float)go2[1];
+        // bf16 -> f32 is a 16-bit shift; done on the integer words (a bf16x2 bit_cast of two different words was folded
+        // into one by the compiler: both pairs came out as (i, f))
+        const float s_i = __uint_as_float(P.rec[0] << 16), s_f = __uint_as_float(P.rec[0] & 0xffff0000u);
+        const float s_g = __uint_as_float(P.rec[1] << 16), s_o = __uint_as_float(P.rec[1] & 0xffff0000u);
         const float c_prev = __uint_as_float(P.rec[2]), tc = __uint_as_float(P.rec[3]);
         float dpre[4];
         {
