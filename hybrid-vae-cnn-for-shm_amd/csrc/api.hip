@@ -240,7 +240,10 @@ extern "C" int shm_vae_plan_create(const shm_vae_config* cfg, int32_t B, int32_t
         size_t gp = 0;
         auto upd = [&](int R, int M, int N) { const size_t e = gemm_tn_partial_elems(R, M, N); if (e > gp) gp = e; };
         upd((int)BT, H, D); upd((int)BT, 4 * H, H); upd((int)BT, 4 * H, D); upd(B, 4 * H, H); upd(B, H, Z); upd(B, Z, H);
-        if (bf) { const size_t e = gemm_tn_bf16_partial_elems((int)(qt * SHM_WPT * T), 4 * H, H); if (e > gp) gp = e; }
+        if (bf) {
+            size_t e = gemm_tn_bf16_partial_elems((int)(qt * SHM_WPT * T), 4 * H, H, 2); if (e > gp) gp = e;
+            e = gemm_tn_bf16_partial_elems((int)(qt * SHM_WPT * T), 4 * H, H, 1); if (e > gp) gp = e;
+        }
         p->gemm_partial_elems = gp;
         p->narrow_scratch = take(narrow_tn_scratch_elems(4 * H, D));
         p->gemm_partial = take(gp > 0 ? gp : 1);
@@ -404,13 +407,13 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
     const HeadBufs hb = head_bufs(p, ws);
 
     const bool bf = c.precision == SHM_PREC_BF16;
-    // wide products on bf16 operands (A = dpre_seq, B = an h sequence): bf16 MFMA GEMM
-    auto gemm_bf = [&](const void* A, int lda, int M, const void* Bm, int ldb, int N, int R, float* C, int shift_T, float dp,
-                       uint32_t stack) -> int {
+    // wide products on bf16 operands: dW_ih = dpre^T x_in (dropout re-applied) and dW_hh = dpre^T h_{t-1} in ONE launch (A read once)
+    auto gemm_bf = [&](const void* A, int M, const void* Bin, float* Cin, float dp, uint32_t stack, const void* Bh, float* Chh, int R) -> int {
         GemmTnArgsB g;
         memset(&g, 0, sizeof(g));
-        g.A = A; g.lda = lda; g.Bm = Bm; g.ldb = ldb; g.b_f32 = 0; g.C = C; g.R = R; g.M = M; g.N = N;
-        g.shift_T = shift_T; g.shift_rows = SHM_WPT;         // tile-blocked rows: step t-1 of the same window is SHM_WPT rows back
+        g.A = A; g.lda = M; g.ldb = H; g.R = R; g.M = M; g.N = H; g.shift_rows = SHM_WPT;
+        if (Bin) { g.NB = 2; g.Bm = Bin; g.C = Cin; g.shift_T = 0; g.Bm2 = Bh; g.C2 = Chh; g.shift_T2 = T; }
+        else { g.NB = 1; g.Bm = Bh; g.C = Chh; g.shift_T = T; }
         g.drop_p = dp; g.drop_seed = p->drop_seed; g.drop_stack = stack;
         g.partial = at<float>(ws, p->gemm_partial); g.partial_elems = p->gemm_partial_elems;
         return launch_gemm_tn_bf16(g, s);
@@ -470,9 +473,11 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
                 KernelTimer kt(gnm, s);
                 const void* dps = at<char>(ws, p->dpre_seq);
                 const int Rt = ceil_div(B, SHM_WPT) * SHM_WPT * T;   // rows incl. tile padding (padding rows of dpre are exactly zero)
-                if ((r = gemm_bf(dps, G, G, at<char>(ws, st[l].h_seq), H, H, Rt, grads + st[l].w_hh, T, 0.f, 0))) return r;
                 if (l > 0) {
-                    if ((r = gemm_bf(dps, G, G, at<char>(ws, st[l - 1].h_seq), H, H, Rt, grads + st[l].w_ih, 0, drop, stack))) return r;
+                    if ((r = gemm_bf(dps, G, at<char>(ws, st[l - 1].h_seq), grads + st[l].w_ih, drop, stack, at<char>(ws, st[l].h_seq),
+                                     grads + st[l].w_hh, Rt))) return r;
+                } else if ((r = gemm_bf(dps, G, nullptr, nullptr, 0.f, 0, at<char>(ws, st[l].h_seq), grads + st[l].w_hh, Rt))) return r;
+                if (l > 0) {
                 } else if (st[l].in_const) {
                     if ((r = gemm(dpre_tsum, G, G, hb.h0, H, H, B, grads + st[l].w_ih, 0, 0, 0.f, 0))) return r;
                 } else {

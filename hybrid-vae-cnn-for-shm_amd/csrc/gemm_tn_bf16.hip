@@ -1,19 +1,24 @@
-// gemm_tn_bf16.hip — weight-gradient GEMM  C[M,N] = sum_r A[r,M]^T B[r,N]  on bf16 MFMA (v_mfma_f32_16x16x32_bf16),
-// fp32 accumulate; gfx950.  bf16 twin of gemm_tn.hip for the wide products (N = H) of the deferred BPTT half
-// (reference: autograd accumulation into weight_ih/weight_hh.grad, 4DOF/Scripts/03_train_vae.py:269).
+// gemm_tn_bf16.hip — weight-gradient GEMM on bf16 MFMA (v_mfma_f32_16x16x32_bf16), fp32 accumulate; gfx950.
+//   C_k[M,N] = sum_r A[r,M]^T B_k[r,N],  k = 0..NB-1   (one launch serves every product that shares A)
+// The deferred half of BPTT (reference: autograd accumulation into weight_ih/weight_hh.grad, 4DOF/Scripts/03_train_vae.py:269):
+// A = dpre_seq[R,4H], B_0 = the layer input sequence (inter-layer dropout mask re-applied), B_1 = the layer's own h
+// sequence taken one step back (h_{t-1}).  R = 131 072 rows at the north-star shape against a 512 x 128 output, so the
+// kernel is HBM-bound on A: both products of a layer run in ONE launch and A is read once.
 //
-// Both operands arrive K-major (row = contraction index r) — the layout the LSTM kernels write coalesced — while an
-// MFMA fragment wants 8 consecutive k per lane.  The tiles are staged in LDS exactly as they sit in HBM
-// ([32 rows][128 cols] bf16, 16-byte row pad) and every fragment is formed by two ds_read_b64_tr_b16 transpose
-// reads (4 rows x 16 columns each): no shuffles, no second layout in HBM.
-// Workgroup = 4 waves (2x2), tile 128x128, wave 64x64 = 4x4 MFMA tiles; split-K over r with an ordered reduction.
+// Both operands arrive K-major (row = contraction index) — the layout the LSTM kernels write coalesced — while an MFMA
+// fragment wants 8 consecutive k per lane: the tiles are staged in LDS exactly as they sit in HBM ([64 rows][128 cols]
+// bf16, 16-byte row pad) and every fragment is formed by two ds_read_b64_tr_b16 transpose reads (4 rows x 16 columns).
+// Workgroup = 4 waves (2x2), tile 128 x 128, wave 64 x 64 = 4 x 4 MFMA tiles, 64 rows (two k-steps) per stage; the next
+// stage's global loads are issued into registers before the current stage is consumed.  Split-K over r with partial tiles
+// summed in a fixed order (reduce_partials): deterministic.  Blocks of one split share A and B, so the 1-D grid is
+// dealt so that they land on the same XCD (blockIdx % 8 — a speed hint only, nothing depends on it).
 #include "kernels.hpp"
 
 namespace shm {
 
 namespace {
 
-constexpr int KC = 32, MT = 128, NT = 128, LD = 136;    // LD*2 B = 272: 2-way at worst on the transpose reads
+constexpr int KC = 64, MT = 128, NT = 128, LD = 136;    // LD*2 B = 272: 2-way at worst on the transpose reads
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -25,35 +30,29 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* p_lo, const bf16_t* p_hi
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <typename T>
-__device__ __forceinline__ bf16x8 load8(const T* p);
-template <>
-__device__ __forceinline__ bf16x8 load8<bf16_t>(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
-template <>
-__device__ __forceinline__ bf16x8 load8<float>(const float* p) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
-    const bf16x4 x = cvt_bf16x4(a), y = cvt_bf16x4(b);
-    return __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7);
-}
-
-template <typename TB>
-__global__ void __launch_bounds__(256) gemm_tn_bf16_kernel(GemmTnArgsB a, int tiles_n, int rows_per_split, int nsplit) {
+__global__ void __launch_bounds__(256) gemm_tn_bf16_kernel(GemmTnArgsB a, int tiles_m, int tiles_n, int rows_per_split, int nsplit) {
     __shared__ __attribute__((aligned(16))) bf16_t sA[KC * LD];
     __shared__ __attribute__((aligned(16))) bf16_t sB[KC * LD];
     const bf16_t* A = reinterpret_cast<const bf16_t*>(a.A);
-    const TB* Bm = reinterpret_cast<const TB*>(a.Bm);
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3, i16 = lane & 15;
     const int wm = w >> 1, wn = w & 1;
-    const int tile = blockIdx.x, tm = tile / tiles_n, tn = tile % tiles_n;
+    // 1-D grid -> (split, tile): all tiles of a split on one XCD (blockIdx % 8)
+    const int tiles = tiles_m * tiles_n * a.NB;
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int tile = local % tiles, split = (local / tiles) * 8 + xcd;
+    if (split >= nsplit) return;
+    const int kb = tile / (tiles_m * tiles_n), tmn = tile - kb * tiles_m * tiles_n, tm = tmn / tiles_n, tn = tmn - tm * tiles_n;
     const int m0 = tm * MT, n0 = tn * NT;
-    const int split = blockIdx.y;
+    const bf16_t* Bm = reinterpret_cast<const bf16_t*>(kb == 0 ? a.Bm : a.Bm2);
+    const int shift_T = kb == 0 ? a.shift_T : a.shift_T2;
+    const float drop_p = kb == 0 ? a.drop_p : 0.f;
     const int r_begin = split * rows_per_split, r_end = min(a.R, r_begin + rows_per_split);
 
-    const uint32_t thr = drop_threshold(a.drop_p);
-    const bool drop = a.drop_p > 0.f;
-    const float dscale = drop ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    const uint32_t thr = drop_threshold(drop_p);
+    const bool drop = drop_p > 0.f;
+    const float dscale = drop ? 1.0f / (1.0f - drop_p) : 1.0f;
     const bf16x8 zero8 = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
 
     f32x4 acc[4][4];
@@ -62,52 +61,71 @@ __global__ void __launch_bounds__(256) gemm_tn_bf16_kernel(GemmTnArgsB a, int ti
 #pragma unroll
         for (int jn = 0; jn < 4; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // transpose-read addresses: lane 4q'+p of a 16-lane group supplies row q', columns 4p..4p+3 of the 4x16 block
-    const int tr_row = 8 * g + qq, tr_col = 4 * pp;
-
-    for (int r0 = r_begin; r0 < r_end; r0 += KC) {
+    // staging: 64 rows x 128 cols = 1024 chunks of 16 B per operand, 4 per thread; chunk e -> (row e/16, cols 8*(e%16)..)
+    bf16x8 ra[4], rb[4];
+    auto load_stage = [&](int r0) {
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
+        for (int it = 0; it < 4; ++it) {
             const int e = tid + it * 256, row = e >> 4, c8 = (e & 15) * 8, r = r0 + row;
-            bf16x8 va = zero8, vb = zero8;
+            ra[it] = zero8; rb[it] = zero8;
             if (r < r_end) {
-                if (m0 + c8 < a.M) va = *reinterpret_cast<const bf16x8*>(A + (size_t)r * a.lda + m0 + c8);
+                if (m0 + c8 < a.M) ra[it] = *reinterpret_cast<const bf16x8*>(A + (size_t)r * a.lda + m0 + c8);
                 if (n0 + c8 < a.N) {
-                    if (a.shift_T > 0) {     // h_{t-1}: rows are tile-blocked (row = (tile*T + t)*16 + j) -> 16 rows back, zero at t = 0
-                        if ((r / a.shift_rows) % a.shift_T != 0) vb = load8<TB>(Bm + (size_t)(r - a.shift_rows) * a.ldb + n0 + c8);
+                    if (shift_T > 0) {     // h_{t-1}: rows are tile-blocked -> shift_rows back, zero at t = 0
+                        if ((r / a.shift_rows) % shift_T != 0) rb[it] = *reinterpret_cast<const bf16x8*>(Bm + (size_t)(r - a.shift_rows) * a.ldb + n0 + c8);
                     } else {
-                        vb = load8<TB>(Bm + (size_t)r * a.ldb + n0 + c8);
+                        rb[it] = *reinterpret_cast<const bf16x8*>(Bm + (size_t)r * a.ldb + n0 + c8);
                         if (drop) {
                             const uint32_t idx = (uint32_t)((size_t)r * a.N + n0 + c8);
 #pragma unroll
                             for (int k = 0; k < 8; ++k)
-                                vb[k] = drop_hash(a.drop_seed, a.drop_stack, idx + k) >= thr ? (bf16_t)((float)vb[k] * dscale) : (bf16_t)0.f;
+                                rb[it][k] = drop_hash(a.drop_seed, a.drop_stack, idx + k) >= thr ? (bf16_t)((float)rb[it][k] * dscale) : (bf16_t)0.f;
                         }
                     }
                 }
             }
-            *reinterpret_cast<bf16x8*>(sA + row * LD + c8) = va;
-            *reinterpret_cast<bf16x8*>(sB + row * LD + c8) = vb;
         }
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int e = tid + it * 256, row = e >> 4, c8 = (e & 15) * 8;
+            *reinterpret_cast<bf16x8*>(sA + row * LD + c8) = ra[it];
+            *reinterpret_cast<bf16x8*>(sB + row * LD + c8) = rb[it];
+        }
+    };
+
+    // transpose-read addresses: lane 4q'+p of a 16-lane group supplies row q', columns 4p..4p+3 of the 4x16 block
+    const int tr_row = 8 * g + qq, tr_col = 4 * pp;
+
+    load_stage(r_begin);
+    for (int r0 = r_begin; r0 < r_end; r0 += KC) {
+        store_stage();
         __syncthreads();
-        bf16x8 af[4], bfr[4];
+        if (r0 + KC < r_end) load_stage(r0 + KC);            // next stage in flight while this one is consumed
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bf16_t* p = sA + tr_row * LD + wm * 64 + i * 16 + tr_col;
-            af[i] = tr_frag(p, p + 4 * LD);
+        for (int ks = 0; ks < KC / 32; ++ks) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bf16_t* p = sA + (ks * 32 + tr_row) * LD + wm * 64 + i * 16 + tr_col;
+                af[i] = tr_frag(p, p + 4 * LD);
+            }
+#pragma unroll
+            for (int jn = 0; jn < 4; ++jn) {
+                const bf16_t* p = sB + (ks * 32 + tr_row) * LD + wn * 64 + jn * 16 + tr_col;
+                bfr[jn] = tr_frag(p, p + 4 * LD);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jn = 0; jn < 4; ++jn) acc[i][jn] = mfma_bf16_16x16x32(af[i], bfr[jn], acc[i][jn]);
         }
-#pragma unroll
-        for (int jn = 0; jn < 4; ++jn) {
-            const bf16_t* p = sB + tr_row * LD + wn * 64 + jn * 16 + tr_col;
-            bfr[jn] = tr_frag(p, p + 4 * LD);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int jn = 0; jn < 4; ++jn) acc[i][jn] = mfma_bf16_16x16x32(af[i], bfr[jn], acc[i][jn]);
         __syncthreads();
     }
 
+    float* C = kb == 0 ? a.C : a.C2;
+    float* dst = nsplit == 1 ? C : a.partial + ((size_t)split * a.NB + kb) * a.M * a.N;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -115,20 +133,17 @@ __global__ void __launch_bounds__(256) gemm_tn_bf16_kernel(GemmTnArgsB a, int ti
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wm * 64 + i * 16 + g * 4 + r, n = n0 + wn * 64 + jn * 16 + i16;
-                if (m < a.M && n < a.N) {
-                    float* dst = nsplit == 1 ? a.C : a.partial + (size_t)split * a.M * a.N;
-                    dst[(size_t)m * a.N + n] = acc[i][jn][r];
-                }
+                if (m < a.M && n < a.N) dst[(size_t)m * a.N + n] = acc[i][jn][r];
             }
 }
 
 struct Geo { int tiles_m, tiles_n, nsplit, rows_per_split; };
-Geo geometry(int R, int M, int N) {
+Geo geometry(int R, int M, int N, int NB) {
     Geo g;
     g.tiles_m = ceil_div(M, MT); g.tiles_n = ceil_div(N, NT);
-    const int tiles = g.tiles_m * g.tiles_n;
-    int nsplit = 512 / tiles;
-    const int max_split = ceil_div(R, 8 * KC);
+    const int tiles = g.tiles_m * g.tiles_n * NB;
+    int nsplit = 512 / tiles;                         // ~2 workgroups per CU, each with a stage in flight
+    const int max_split = ceil_div(R, 4 * KC);
     if (nsplit > max_split) nsplit = max_split;
     if (nsplit < 1) nsplit = 1;
     g.rows_per_split = round_up(ceil_div(R, nsplit), KC);
@@ -138,25 +153,31 @@ Geo geometry(int R, int M, int N) {
 
 }  // namespace
 
-size_t gemm_tn_bf16_partial_elems(int R, int M, int N) {
-    const Geo g = geometry(R, M, N);
-    return g.nsplit > 1 ? (size_t)g.nsplit * M * N : 0;
+size_t gemm_tn_bf16_partial_elems(int R, int M, int N, int NB) {
+    const Geo g = geometry(R, M, N, NB);
+    return g.nsplit > 1 ? (size_t)g.nsplit * NB * M * N : 0;
 }
 
 int launch_gemm_tn_bf16(const GemmTnArgsB& a, hipStream_t s) {
-    SHM_REQUIRE(a.R > 0 && a.M > 0 && a.N > 0, SHM_EINVAL, "gemm_tn_bf16: empty shape");
+    SHM_REQUIRE(a.R > 0 && a.M > 0 && a.N > 0 && (a.NB == 1 || a.NB == 2), SHM_EINVAL, "gemm_tn_bf16: bad shape");
     SHM_REQUIRE((a.M & 7) == 0 && (a.N & 7) == 0 && (a.lda & 7) == 0 && (a.ldb & 7) == 0, SHM_EINVAL,
                 "gemm_tn_bf16: M, N, lda, ldb must be multiples of 8 (got %d %d %d %d)", a.M, a.N, a.lda, a.ldb);
-    const Geo g = geometry(a.R, a.M, a.N);
-    SHM_REQUIRE(g.nsplit == 1 || (a.partial && a.partial_elems >= (size_t)g.nsplit * a.M * a.N), SHM_EWORKSPACE,
+    SHM_REQUIRE(a.NB == 1 || (a.Bm2 && a.C2), SHM_EINVAL, "gemm_tn_bf16: second operand missing");
+    const Geo g = geometry(a.R, a.M, a.N, a.NB);
+    SHM_REQUIRE(g.nsplit == 1 || (a.partial && a.partial_elems >= (size_t)g.nsplit * a.NB * a.M * a.N), SHM_EWORKSPACE,
                 "gemm_tn_bf16: split-K scratch too small");
-    dim3 grid(g.tiles_m * g.tiles_n, g.nsplit);
-    if (a.b_f32)
-        hipLaunchKernelGGL(gemm_tn_bf16_kernel<float>, grid, dim3(256), 0, s, a, g.tiles_n, g.rows_per_split, g.nsplit);
-    else
-        hipLaunchKernelGGL(gemm_tn_bf16_kernel<bf16_t>, grid, dim3(256), 0, s, a, g.tiles_n, g.rows_per_split, g.nsplit);
+    const int tiles = g.tiles_m * g.tiles_n * a.NB;
+    const int grid = round_up(g.nsplit, 8) * tiles;
+    hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(grid), dim3(256), 0, s, a, g.tiles_m, g.tiles_n, g.rows_per_split, g.nsplit);
     SHM_LAUNCH_CHECK();
-    if (g.nsplit > 1) return launch_reduce_partials(a.partial, g.nsplit, (size_t)a.M * a.N, a.C, nullptr, s);
+    if (g.nsplit > 1) {
+        // partial[split][kb][M*N]: reduce each product with a stride of NB*M*N between splits
+        for (int kb = 0; kb < a.NB; ++kb) {
+            int rc = launch_reduce_partials_strided(a.partial + (size_t)kb * a.M * a.N, g.nsplit, (size_t)a.M * a.N, (size_t)a.NB * a.M * a.N,
+                                                    kb == 0 ? a.C : a.C2, s);
+            if (rc) return rc;
+        }
+    }
     return SHM_OK;
 }
 

@@ -97,6 +97,8 @@ int launch_narrow_tn(const void* A, int a_bf16, int lda, int M, const float* Bn,
 size_t narrow_tn_scratch_elems(int M, int N);
 // out[i] (and out1[i]) = sum_p partial[p*n + i], p < nparts (fixed order)
 int launch_reduce_partials(const float* partial, int nparts, size_t n, float* out0, float* out1, hipStream_t s);
+// same with an explicit element stride between consecutive partials
+int launch_reduce_partials_strided(const float* partial, int nparts, size_t n, size_t stride, float* out0, hipStream_t s);
 
 // ==== bf16 throughput path (fp32 accumulate / cell state / master weights) ===================================
 // Windows per workgroup of the recurrent kernels ("quad tiles", lstm_fwd_bf16.hip).  Sequence buffers of this path are
@@ -136,17 +138,19 @@ int launch_lstm_bwd_bf16(int H, const LstmBwdArgsB& a, hipStream_t s);      // r
 int launch_dx_gemm_bf16(int H, const LstmBwdArgsB& a, hipStream_t s);       // time-parallel part: dx_seq = dpre_seq . W_ih
 
 struct GemmTnArgsB {
-    const void* A; int lda;        // [R, M] bf16
-    const void* Bm; int ldb;       // [R, N] bf16 or fp32 (b_f32)
-    int b_f32;
-    float* C;                      // [M, N] dense
+    const void* A; int lda;        // [R, M] bf16 (dpre_seq)
+    const void* Bm; int ldb;       // [R, N] bf16, product 0 (dropout mask optional)
+    const void* Bm2;               // [R, N] bf16, product 1 (NB == 2)
+    float* C; float* C2;           // [M, N] dense outputs of product 0 / 1
+    int NB;                        // 1 or 2 products sharing A
     int R, M, N;
-    int shift_T, shift_rows;       // shift_T > 0: B row r is taken from row r - shift_rows, zero when (r / shift_rows) % shift_T == 0
-    float drop_p; uint64_t drop_seed; uint32_t drop_stack;
+    int shift_T, shift_T2;         // per product: > 0 -> B row r is taken from row r - shift_rows, zero when (r / shift_rows) % shift_T == 0
+    int shift_rows;
+    float drop_p; uint64_t drop_seed; uint32_t drop_stack;     // dropout on product 0's B (element index r*N + n)
     float* partial; size_t partial_elems;
 };
 int launch_gemm_tn_bf16(const GemmTnArgsB& a, hipStream_t s);
-size_t gemm_tn_bf16_partial_elems(int R, int M, int N);
+size_t gemm_tn_bf16_partial_elems(int R, int M, int N, int NB);
 
 int launch_pack_fwd_bf16(const float* W, int H, int K, bf16_t* dst, hipStream_t s);
 int launch_pack_bwd_bf16(const float* W, int H, int M, bf16_t* dst, hipStream_t s);

@@ -257,6 +257,66 @@ __global__ void __launch_bounds__(256) out_fwd_kernel(int T, int D, int H, const
     if (threadIdx.x == 0 && score) score[b] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)(T * D);
 }
 
+// bf16 path: recon^T = W_out . h^T on MFMA.  One workgroup = one SHM_WPT-window tile: its T*WPT rows of h_seq are one
+// contiguous block; a wave takes 16 rows (= 4 steps x 4 windows) per MFMA chain, A = h rows straight from HBM (16-byte
+// fragments), B = W_out^T fragments in registers.  Accumulator row 4q+r <-> (step t0+q, window r), column j = channel, so
+// each lane adds the squared error of ONE window (r) and the per-window score needs no atomics.
+template <int H>
+__global__ void __launch_bounds__(256) out_fwd_mfma_kernel(int B, int T, int D, const bf16_t* __restrict__ h_seq,
+                                                           const float* __restrict__ Wout, const float* __restrict__ bout,
+                                                           const float* __restrict__ x, float* __restrict__ recon,
+                                                           float* __restrict__ score) {
+    static_assert(SHM_WPT == 4, "row <-> (step, window) mapping below assumes 4-window tiles");
+    constexpr int KS = H / 32;
+    __shared__ float red[4][4][64];
+    const int tile = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
+    bf16x8 wf[KS];                      // B operand: lane (q,j) holds W_out[j][8q + 32s .. +7] (zero for j >= D)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wf[s][e] = (bf16_t)(j < D ? Wout[(size_t)j * H + 8 * q + 32 * s + e] : 0.f);
+    }
+    const float bias = j < D ? bout[j] : 0.f;
+    const int n_groups = (T * 4 + 15) / 16;                           // 16-row groups of this tile (4 steps each)
+    const bf16_t* hb = h_seq + (size_t)tile * T * 4 * H;
+    float sq[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int grp = w; grp < n_groups; grp += 4) {
+        const int row = grp * 16 + j;                                 // A operand row supplied by this lane
+        const bool rv = row < T * 4;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            bf16x8 af = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+            if (rv) af = *reinterpret_cast<const bf16x8*>(hb + (size_t)row * H + 8 * q + 32 * s);
+            acc = mfma_bf16_16x16x32(af, wf[s], acc);
+        }
+        const int t = grp * 4 + q;                                    // accumulator rows 4q + r: step t, window r
+        if (j < D && t < T) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int b = tile * 4 + r;
+                if (b < B) {
+                    const size_t o = ((size_t)b * T + t) * D + j;
+                    const float rc = acc[r] + bias;
+                    if (recon) recon[o] = rc;
+                    const float e = x[o] - rc;
+                    sq[r] = fmaf(e, e, sq[r]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[w][r][lane] = sq[r];
+    __syncthreads();
+    if (threadIdx.x < 4 && score) {                                   // fixed-order sum: deterministic
+        const int r = threadIdx.x, b = tile * 4 + r;
+        float tot = 0.f;
+        for (int ww = 0; ww < 4; ++ww)
+            for (int l = 0; l < 64; ++l) tot += red[ww][r][l];
+        if (b < B) score[b] = tot / (float)(T * D);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ loss + its gradients
 __global__ void __launch_bounds__(256) vae_loss_kernel(int B, int T, int D, int Z, const float* __restrict__ x,
                                                        const float* __restrict__ recon, const float* __restrict__ mu,
@@ -308,13 +368,13 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ A
 }
 // block = 32 outputs x 8 partial-groups: group g sums partials g, g+8, ... (4 independent chains), then a fixed-order
 // combine over the groups — deterministic, and latency-tolerant even for few outputs and many partials.
-__global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __restrict__ partial, int nparts, size_t n,
+__global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __restrict__ partial, int nparts, size_t n_out, size_t n,
                                                               float* __restrict__ out0, float* __restrict__ out1) {
     __shared__ float red[8][32];
     const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const size_t i = (size_t)blockIdx.x * 32 + o;
+    const size_t i = (size_t)blockIdx.x * 32 + o;          // n = element stride between partials, n_out = outputs
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    if (i < n) {
+    if (i < n_out) {
         int p = grp;
         for (; p + 24 < nparts; p += 32) {
             s0 += partial[(size_t)p * n + i];
@@ -326,7 +386,7 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __res
     }
     red[grp][o] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (grp == 0 && i < n) {
+    if (grp == 0 && i < n_out) {
         const float v = ((red[0][o] + red[1][o]) + (red[2][o] + red[3][o])) + ((red[4][o] + red[5][o]) + (red[6][o] + red[7][o]));
         out0[i] = v;
         if (out1) out1[i] = v;
@@ -495,8 +555,13 @@ int launch_head_grads(int B, int H, int Z, int layer_norm, const HeadBufs& hb, f
 int launch_out_fwd(int B, int T, int D, int H, const void* h_seq, int h_bf16, const float* Wout, const float* bout, const float* x,
                    float* recon, float* score, hipStream_t s) {
     SHM_REQUIRE(D <= DMAX && H <= HMAX, SHM_EINVAL, "out: D=%d (<=%d) H=%d unsupported", D, DMAX, H);
-    if (h_bf16)
-        hipLaunchKernelGGL((out_fwd_kernel<bf16_t, true>), dim3(B), dim3(256), 0, s, T, D, H, (const bf16_t*)h_seq, Wout, bout, x, recon, score);
+    if (h_bf16) {
+        const int tiles = ceil_div(B, SHM_WPT);
+        const bf16_t* hs = (const bf16_t*)h_seq;
+        if (H == 128) hipLaunchKernelGGL(out_fwd_mfma_kernel<128>, dim3(tiles), dim3(256), 0, s, B, T, D, hs, Wout, bout, x, recon, score);
+        else if (H == 64) hipLaunchKernelGGL(out_fwd_mfma_kernel<64>, dim3(tiles), dim3(256), 0, s, B, T, D, hs, Wout, bout, x, recon, score);
+        else hipLaunchKernelGGL(out_fwd_mfma_kernel<32>, dim3(tiles), dim3(256), 0, s, B, T, D, hs, Wout, bout, x, recon, score);
+    }
     else
         hipLaunchKernelGGL((out_fwd_kernel<float, false>), dim3(B), dim3(256), 0, s, T, D, H, (const float*)h_seq, Wout, bout, x, recon, score);
     SHM_LAUNCH_CHECK();
@@ -512,7 +577,12 @@ int launch_vae_loss(int B, int T, int D, int Z, const float* x, const float* rec
 }
 size_t colsum_scratch_elems(int R, int N) { return (size_t)ceil_div(R, CS_ROWS) * N; }
 int launch_reduce_partials(const float* partial, int nparts, size_t n, float* out0, float* out1, hipStream_t s) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, partial, nparts, n, out0, out1);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, partial, nparts, n, n, out0, out1);
+    SHM_LAUNCH_CHECK();
+    return SHM_OK;
+}
+int launch_reduce_partials_strided(const float* partial, int nparts, size_t n, size_t stride, float* out0, hipStream_t s) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, partial, nparts, n, stride, out0, (float*)nullptr);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
