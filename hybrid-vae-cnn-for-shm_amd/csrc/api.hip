@@ -45,7 +45,8 @@ struct LayerInst {
     bool in_const = false;
     int64_t w_ih = 0, w_hh = 0, b_ih = 0, b_hh = 0;      // element offsets into the flat parameter buffer
     size_t Wx = 0, Wh = 0, bsum = 0, WhT = 0, WxT = 0;   // byte offsets into the workspace (packed operands)
-    size_t h_seq = 0, saved = 0, saved_c = 0;            // bf16 path: saved = gates (bf16), saved_c = cell state (fp32)
+    size_t h_seq = 0, saved = 0, saved_c = 0;            // bf16 path: saved = BPTT records
+    size_t xdrop = 0;                                    // bf16 path, layers >= 1: dropout-masked input sequence
 };
 
 }  // namespace shm
@@ -209,6 +210,7 @@ extern "C" int shm_vae_plan_create(const shm_vae_config* cfg, int32_t B, int32_t
                 li.Wx = take_bytes(2 * fwd_pack_elems_bf16(H, li.In));
                 li.Wh = take_bytes(2 * fwd_pack_elems_bf16(H, H));
                 li.h_seq = take_bytes(2 * Rq * H);                        // whole tiles: unconditional stores in the kernel
+                if (l > 0 && cfg->dropout > 0.f) li.xdrop = take_bytes(2 * Rq * H);   // train-mode forward writes its masked input here
                 if (training) {
                     li.WhT = take_bytes(2 * bwd_pack_elems_bf16(H, H));
                     if (l > 0) li.WxT = take_bytes(2 * bwd_pack_elems_bf16(H, li.In));
@@ -329,6 +331,7 @@ extern "C" int shm_vae_forward(shm_vae_plan* p, const float* x, const float* eps
                 a.h_seq = at<bf16_t>(ws, st[l].h_seq);
                 a.h_last = (l == L - 1) ? h_last : nullptr;
                 a.sv_g = save ? at<bf16_t>(ws, st[l].saved) : nullptr;
+                a.xdrop = (l > 0 && c.dropout > 0.f) ? at<bf16_t>(ws, st[l].xdrop) : nullptr;
                 a.B = B; a.T = T; a.In = st[l].In; a.in_const = st[l].in_const ? 1 : 0;
                 a.drop_p = l > 0 ? drop : 0.f; a.drop_seed = drop_seed; a.drop_stack = stack;
                 KernelTimer kt(nm, s);
@@ -473,9 +476,9 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
                 KernelTimer kt(gnm, s);
                 const void* dps = at<char>(ws, p->dpre_seq);
                 const int Rt = ceil_div(B, SHM_WPT) * SHM_WPT * T;   // rows incl. tile padding (padding rows of dpre are exactly zero)
-                if (l > 0) {
-                    if ((r = gemm_bf(dps, G, at<char>(ws, st[l - 1].h_seq), grads + st[l].w_ih, drop, stack, at<char>(ws, st[l].h_seq),
-                                     grads + st[l].w_hh, Rt))) return r;
+                if (l > 0) {      // with dropout the forward left the masked input in xdrop: no re-hashing in the GEMM
+                    const void* xin = drop > 0.f ? at<char>(ws, st[l].xdrop) : at<char>(ws, st[l - 1].h_seq);
+                    if ((r = gemm_bf(dps, G, xin, grads + st[l].w_ih, 0.f, stack, at<char>(ws, st[l].h_seq), grads + st[l].w_hh, Rt))) return r;
                 } else if ((r = gemm_bf(dps, G, nullptr, nullptr, 0.f, 0, at<char>(ws, st[l].h_seq), grads + st[l].w_hh, Rt))) return r;
                 if (l > 0) {
                 } else if (st[l].in_const) {

@@ -116,6 +116,7 @@ struct LstmFwdArgsB {
     const bf16_t* Wx; const bf16_t* Wh;
     const float* bias;
     bf16_t* h_seq;          // tile-blocked [ceil(B/WPT)*T*WPT, H] bf16
+    bf16_t* xdrop;          // same layout: the dropout-masked input sequence (written when drop_p > 0), operand of the dW_ih GEMM
     float* h_last;          // [B,H] fp32 or nullptr
     bf16_t* sv_g;           // BPTT records [tile][T][H/16][64] x 16 B {i,f|g,o bf16, c_{t-1}, tanh(c_t) fp32} or nullptr
     float* sv_c;            // unused (kept for ABI stability of the struct)

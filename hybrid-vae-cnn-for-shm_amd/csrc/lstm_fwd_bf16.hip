@@ -107,6 +107,9 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
                 const uint32_t idx = (uint32_t)((((size_t)tile * T + t) * WPT + xjj) * H + xc8);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = drop_hash(a.drop_seed, a.drop_stack, idx + e) >= thr ? (bf16_t)((float)v[e] * dscale) : (bf16_t)0.f;
+                // keep the masked input for the dW_ih GEMM (same tile-blocked layout as the source): hashing it again there
+                // costs more VALU than the GEMM's MFMAs
+                if (tid < NCH) *reinterpret_cast<bf16x8*>(a.xdrop + ((size_t)tile * T + t) * WPT * H + (size_t)xc * 8) = v;
             }
             if (tid < NCH) *reinterpret_cast<bf16x8*>(xl + x_img_off) = v;
         }
@@ -247,6 +250,7 @@ int launch_h(const LstmFwdArgsB& a, hipStream_t s) {
         return launch_x<H, 1, true, false>(a, s);
     }
     SHM_REQUIRE(a.In == H, SHM_EINVAL, "lstm_fwd_bf16: layer input width %d must equal hidden width %d", a.In, H);
+    SHM_REQUIRE(!(a.drop_p > 0.f && !a.in_const) || a.xdrop != nullptr, SHM_EINVAL, "lstm_fwd_bf16: dropout needs the xdrop buffer");
     if (a.in_const) return launch_x<H, H / 32, false, true>(a, s);
     return launch_x<H, H / 32, false, false>(a, s);
 }
