@@ -277,6 +277,28 @@ extern "C" int shm_vae_pack_weights(shm_vae_plan* p, const float* params, void* 
     hipStream_t s = (hipStream_t)stream;
     const int H = p->cfg.hidden_dim, L = p->cfg.num_layers;
     SHM_HIP_CHECK(hipMemcpyAsync(at<float>(ws, p->params_copy), params, sizeof(float) * p->n_params, hipMemcpyDeviceToDevice, s));
+    if (p->cfg.precision == SHM_PREC_BF16) {          // bf16 path: every re-layout in one launch
+        PackJobs jobs;
+        jobs.n = 0;
+        auto add = [&](const float* src, const float* src2, void* dst, int kind, int K) {
+            PackJob& j = jobs.job[jobs.n++];
+            j.src = src; j.src2 = src2; j.dst = dst; j.kind = kind; j.H = H; j.K = K;
+        };
+        for (int l = 0; l < L; ++l)
+            for (int st = 0; st < 2; ++st) {
+                const LayerInst& li = st == 0 ? p->enc[l] : p->dec[l];
+                add(params + li.b_ih, params + li.b_hh, at<float>(ws, li.bsum), 2, 0);
+                add(params + li.w_ih, nullptr, at<bf16_t>(ws, li.Wx), 0, li.In);
+                add(params + li.w_hh, nullptr, at<bf16_t>(ws, li.Wh), 0, H);
+                if (p->training) {
+                    add(params + li.w_hh, nullptr, at<bf16_t>(ws, li.WhT), 1, H);
+                    if (l > 0) add(params + li.w_ih, nullptr, at<bf16_t>(ws, li.WxT), 1, li.In);
+                }
+            }
+        if ((rc = launch_pack_all(jobs, s))) return rc;
+        p->packed = true;
+        return SHM_OK;
+    }
     for (int l = 0; l < L; ++l) {
         for (int st = 0; st < 2; ++st) {
             const LayerInst& li = st == 0 ? p->enc[l] : p->dec[l];

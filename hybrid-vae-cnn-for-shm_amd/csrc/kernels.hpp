@@ -153,6 +153,10 @@ struct GemmTnArgsB {
 int launch_gemm_tn_bf16(const GemmTnArgsB& a, hipStream_t s);
 size_t gemm_tn_bf16_partial_elems(int R, int M, int N, int NB);
 
+// all bf16 re-layouts + bias sums of one parameter update in a single launch
+struct PackJob { const float* src; const float* src2; void* dst; int kind, H, K; };   // kind 0: fwd operand (K = in width), 1: bwd operand (K = M), 2: bias sum
+struct PackJobs { PackJob job[20]; int n; };
+int launch_pack_all(const PackJobs& jobs, hipStream_t s);
 int launch_pack_fwd_bf16(const float* W, int H, int K, bf16_t* dst, hipStream_t s);
 int launch_pack_bwd_bf16(const float* W, int H, int M, bf16_t* dst, hipStream_t s);
 

@@ -351,12 +351,14 @@ __global__ void __launch_bounds__(256) vae_loss_kernel(int B, int T, int D, int 
 }
 
 // ------------------------------------------------------------------------------------------------ column sums
-constexpr int CS_ROWS = 2048;    // rows per block (grid.y chunks), fixed summation order
+// rows per block: enough chunks to fill the chip (>= ~256 blocks) but at least 32 rows each; fixed summation order
+__host__ __device__ inline int cs_rows(int R) { const int r = (R + 255) / 256; return r < 32 ? 32 : r; }
 __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ A, int lda, int R, int N,
                                                      float* __restrict__ out) {
-    // block: 64 columns x 4 row-groups over one chunk of CS_ROWS rows; writes out[chunk*N + c]
+    // block: 64 columns x 4 row-groups over one chunk of rows; writes out[chunk*N + c]
     __shared__ float red[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    const int CS_ROWS = cs_rows(R);
     const int r0 = blockIdx.y * CS_ROWS, r1 = min(R, r0 + CS_ROWS);
     float s = 0.f;
     if (c < N)
@@ -523,6 +525,37 @@ __global__ void __launch_bounds__(256) pack_bwd_bf16_kernel(const float* __restr
         dst[i] = (bf16_t)(m < M ? W[(size_t)k * M + m] : 0.f);
     }
 }
+// every per-step re-layout of the parameters in ONE launch: blockIdx.y selects the job
+__global__ void __launch_bounds__(256) pack_all_kernel(PackJobs jobs) {
+    const PackJob jb = jobs.job[blockIdx.y];
+    const size_t stride = (size_t)gridDim.x * 256, i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int H = jb.H;
+    if (jb.kind == 0) {            // forward operand, bf16 (layout in kernels.hpp)
+        const int K = jb.K, Kp = (K + 31) & ~31, KQ = Kp >> 2, KS = KQ >> 3;
+        bf16_t* dst = reinterpret_cast<bf16_t*>(jb.dst);
+        for (size_t i = i0; i < (size_t)4 * H * Kp; i += stride) {
+            const int e = i & 7, lane = (i >> 3) & 63;
+            size_t r = i >> 9;
+            const int g = r & 3; r >>= 2;
+            const int s = r % KS, ht = r / KS;
+            const int row = g * H + ht * 16 + (lane & 15), k = (lane >> 4) * KQ + 8 * s + e;
+            dst[i] = (bf16_t)(k < K ? jb.src[(size_t)row * K + k] : 0.f);
+        }
+    } else if (jb.kind == 1) {     // backward operand (W^T), bf16
+        const int M = jb.K, KS = H >> 3, Mp = (M + 15) & ~15;
+        bf16_t* dst = reinterpret_cast<bf16_t*>(jb.dst);
+        for (size_t i = i0; i < (size_t)Mp * 4 * H; i += stride) {
+            const int e = i & 7, lane = (i >> 3) & 63;
+            const size_t r = i >> 9;
+            const int s = r % KS, mt = r / KS;
+            const int k = (lane >> 4) * H + 8 * s + e, m = mt * 16 + (lane & 15);
+            dst[i] = (bf16_t)(m < M ? jb.src[(size_t)k * M + m] : 0.f);
+        }
+    } else {                       // bias sum b_ih + b_hh
+        float* dst = reinterpret_cast<float*>(jb.dst);
+        for (size_t i = i0; i < (size_t)4 * H; i += stride) dst[i] = jb.src[i] + jb.src2[i];
+    }
+}
 __global__ void __launch_bounds__(256) bias_sum_kernel(const float* __restrict__ a, const float* __restrict__ b, int n, float* __restrict__ dst) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) dst[i] = a[i] + b[i];
@@ -575,7 +608,7 @@ int launch_vae_loss(int B, int T, int D, int Z, const float* x, const float* rec
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
-size_t colsum_scratch_elems(int R, int N) { return (size_t)ceil_div(R, CS_ROWS) * N; }
+size_t colsum_scratch_elems(int R, int N) { return (size_t)ceil_div(R, cs_rows(R)) * N; }
 int launch_reduce_partials(const float* partial, int nparts, size_t n, float* out0, float* out1, hipStream_t s) {
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, partial, nparts, n, n, out0, out1);
     SHM_LAUNCH_CHECK();
@@ -587,7 +620,7 @@ int launch_reduce_partials_strided(const float* partial, int nparts, size_t n, s
     return SHM_OK;
 }
 int launch_colsum(const float* A, int lda, int R, int N, float* out0, float* out1, float* scratch, hipStream_t s) {
-    const int chunks = ceil_div(R, CS_ROWS);
+    const int chunks = ceil_div(R, cs_rows(R));
     hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 64), chunks), dim3(256), 0, s, A, lda, R, N, scratch);
     SHM_LAUNCH_CHECK();
     return launch_reduce_partials(scratch, chunks, (size_t)N, out0, out1, s);
@@ -642,6 +675,12 @@ int launch_pack_fwd_bf16(const float* W, int H, int K, bf16_t* dst, hipStream_t 
 int launch_pack_bwd_bf16(const float* W, int H, int M, bf16_t* dst, hipStream_t s) {
     const size_t n = bwd_pack_elems_bf16(H, M);
     hipLaunchKernelGGL(pack_bwd_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, H, M, dst);
+    SHM_LAUNCH_CHECK();
+    return SHM_OK;
+}
+int launch_pack_all(const PackJobs& jobs, hipStream_t s) {
+    if (jobs.n == 0) return SHM_OK;
+    hipLaunchKernelGGL(pack_all_kernel, dim3(64, jobs.n), dim3(256), 0, s, jobs);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
