@@ -16,11 +16,10 @@
 //   * h_t returns to the LDS operand image as bf16; h_seq is tile-blocked row-major (row r' = (tile*T + t)*4 + j) and is
 //     copied out of the completed image one step later as 16-byte coalesced stores; the next layer stages x_t from the same
 //     contiguous 4 x H block;
-//   * x_{t+2..t+4} are prefetched in three rotating register slots; the time loop is branch-free (clamped loads, T % 3
-//     steps peeled, slot use pinned with an empty asm) so the compiler emits one counted s_waitcnt vmcnt per step;
-//   * only W_hh h_{t-1} is on the step's critical path: W_ih x_{t+1} is issued at the END of step t (x_{t+1} has been in
-//     its LDS image — three of them, filled two steps ahead — since the previous barrier), so those MFMAs run while the
-//     wave waits at the barrier and the other waves finish their cell updates.
+//   * x_{t+1..t+3} are prefetched in three rotating register slots; the time loop is branch-free (clamped loads, T % 3
+//     steps peeled, slot use pinned with an empty asm) so the compiler emits one counted s_waitcnt vmcnt per step.
+//     (Issuing W_ih x_{t+1} at the end of step t, ahead of the barrier, was measured SLOWER — 0.29 vs 0.27 ms per layer-1
+//     launch: the two waves of a SIMD share its MFMA pipe, so the extra MFMAs only delay the barrier arrival.)
 #include "kernels.hpp"
 
 namespace shm {
@@ -40,8 +39,8 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
     constexpr int HBUF = 4 * 16 * RSH, XBUF = 4 * 16 * RSX;       // bf16 elements per operand image
     extern __shared__ __attribute__((aligned(16))) bf16_t smem_b[];
     bf16_t* h_lds = smem_b;                     // [2][HBUF]
-    bf16_t* x_lds = smem_b + 2 * HBUF;          // [3][XBUF]: image i holds x_t with t % 3 == i
-    float* scr = reinterpret_cast<float*>(smem_b + 2 * HBUF + 3 * XBUF);   // [NW][4 gates][64] accumulator re-deal scratch
+    bf16_t* x_lds = smem_b + 2 * HBUF;          // [2][XBUF]
+    float* scr = reinterpret_cast<float*>(smem_b + 2 * (HBUF + XBUF));   // [NW][4 gates][64] accumulator re-deal scratch
 
     const int In = a.In, T = a.T, B = a.B;
     const int tid = threadIdx.x, lane = tid & 63, ht = tid >> 6, q = lane >> 4, j = lane & 15;
@@ -51,7 +50,7 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
     const int cb = tile * WPT + cj;
     const bool cvalid = cb < B;
 
-    for (int e = tid; e < 2 * HBUF + 3 * XBUF; e += NTHR) smem_b[e] = (bf16_t)0.f;
+    for (int e = tid; e < 2 * (HBUF + XBUF); e += NTHR) smem_b[e] = (bf16_t)0.f;
 
     // ---- weights -> registers (fragment order, see kernels.hpp)
     bf16x8 wh[4][KSH], wx[4][XK];
@@ -165,11 +164,7 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
         XSlot X;
         x_fetch(X, 0);
         x_commit(X, 0, 0);
-        if (T > 1) { x_fetch(X, 1); x_commit(X, 1, 1); }
         __syncthreads();
-#pragma unroll
-        for (int g = 0; g < 4; ++g) xproj[g] = bias4[g];
-        mma_x(xproj, x_lds);                               // input projection of step 0
     }
 
     float c = 0.f, h = 0.f;
@@ -181,13 +176,19 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
             *reinterpret_cast<bf16x8*>(a.h_seq + ((size_t)tile * T + t_done) * WPT * H + (size_t)xc * 8) =
                 *reinterpret_cast<const bf16x8*>(h_lds + buf * HBUF + h_img_off);
     };
-    // X: slot holding x_{t+2}; committed during the step and refilled with x_{t+5}.  xproj holds b + W_ih x_t on entry.
+    // X: slot holding x_{t+1}; committed at the end of the step and refilled with x_{t+4}
     auto step = [&](XSlot& X, int t) {
         const int cur = t & 1;
         if (t > 0) h_flush(t - 1, cur);                    // h_{t-1} sits complete in h_lds[cur]
         f32x4 acc[4];
+        if constexpr (CONSTIN) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g] = xproj[g];
+            for (int g = 0; g < 4; ++g) acc[g] = xproj[g];
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = bias4[g];
+            mma_x(acc, x_lds + cur * XBUF);
+        }
         mma_h(acc, h_lds + cur * HBUF);
 
         float gate[4];
@@ -199,8 +200,8 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
         h = go * tc;
         h_lds[(cur ^ 1) * HBUF + my_h_off] = (bf16_t)h;
         if constexpr (!CONSTIN) {
-            if (t + 2 < T) x_commit(X, t + 2, (t + 2) % 3);
-            x_fetch(X, t + 5);
+            if (t + 1 < T) x_commit(X, t + 1, cur ^ 1);
+            x_fetch(X, t + 4);
         }
         if constexpr (SAVE) {
             f32x2 a0 = {gi, gf}, a1 = {gg, go};
@@ -211,19 +212,12 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
             rec[3] = __float_as_uint(tc);
             sv[(size_t)t * NW * 64] = rec;
         }
-        if constexpr (!CONSTIN) {
-            if (t + 1 < T) {                               // next step's input projection: off the critical path
-#pragma unroll
-                for (int g = 0; g < 4; ++g) xproj[g] = bias4[g];
-                mma_x(xproj, x_lds + ((t + 1) % 3) * XBUF);
-            }
-        }
         __syncthreads();
     };
     XSlot X0, X1, X2;
     int t = 0;
-    for (int k = T % 3; k > 0; --k, ++t) { x_fetch(X0, t + 2); step(X0, t); }   // peel: the main loop runs whole triples
-    x_fetch(X0, t + 2); x_fetch(X1, t + 3); x_fetch(X2, t + 4);
+    for (int k = T % 3; k > 0; --k, ++t) { x_fetch(X0, t + 1); step(X0, t); }   // peel: the main loop runs whole triples
+    x_fetch(X0, t + 1); x_fetch(X1, t + 2); x_fetch(X2, t + 3);
     __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0) once: only steady-state loads cross the back-edge
     for (; t + 2 < T; t += 3) {
         step(X0, t);
@@ -237,7 +231,7 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
 template <int H, int XK, bool XF32, bool CONSTIN>
 int launch_x(const LstmFwdArgsB& a, hipStream_t s) {
     const int tiles = ceil_div(a.B, WPT);
-    const size_t lds = sizeof(bf16_t) * 4 * 16 * (2 * lds_row_stride(H / 4) + 3 * lds_row_stride(XK * 8)) + sizeof(float) * (H / 16) * 256;
+    const size_t lds = sizeof(bf16_t) * 2 * 4 * 16 * (lds_row_stride(H / 4) + lds_row_stride(XK * 8)) + sizeof(float) * (H / 16) * 256;
     const bool drop = a.drop_p > 0.f && !XF32 && !CONSTIN, save = a.sv_g != nullptr;
     void (*kern)(LstmFwdArgsB);
     if constexpr (XF32 || CONSTIN)
