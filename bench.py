@@ -56,6 +56,26 @@ def kernel_alg_flops(name, B, bf16=False):
     return 0
 
 
+PMC_SUMMARY = ROOT / "profiles" / "r01_bf16_pmc_traffic.json"
+
+
+def pmc_traffic(label, precision):
+    """HBM bytes per launch of the profiled kernel from the committed rocprofv3 --pmc summary (same command, bf16)."""
+    if precision != "bf16" or not PMC_SUMMARY.exists():
+        return None
+    kind, _, inst = label.partition(".")
+    want = {"lstm_fwd": {"enc0": "lstm_fwd_bf16_kernel<128, 1, true", "dec0": "lstm_fwd_bf16_kernel<128, 4, false, false, true",
+                         "enc1": "lstm_fwd_bf16_kernel<128, 4, false, true, false", "dec1": "lstm_fwd_bf16_kernel<128, 4, false, true, false"},
+            "lstm_bwd": {"enc0": "lstm_bwd_bf16_kernel<128, 1>", "dec0": "lstm_bwd_bf16_kernel<128, 1>",
+                         "enc1": "lstm_bwd_bf16_kernel<128, 0>", "dec1": "lstm_bwd_bf16_kernel<128, 2>"}}.get(kind, {}).get(inst)
+    if not want:
+        return None
+    for name, v in json.loads(PMC_SUMMARY.read_text())["kernels"].items():
+        if want in name:
+            return v["hbm_bytes"]
+    return None
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -106,11 +126,14 @@ def cpu_baseline(sample_windows=128, max_steps=3, budget_s=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=2)
-    ap.add_argument("--precision", choices=["bf16", "fp32"], default="fp32")
+    ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16",
+                    help="bf16 (default): bf16 MFMA operands, fp32 accumulate/state/master weights — BASELINE.json configs[1]; "
+                         "fp32: exact-f32 MFMA parity path (1e-4 vs the reference)")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the short fp32 parity-path measurement (N=1 only)")
     args = ap.parse_args()
 
     import torch
@@ -182,7 +205,8 @@ def main():
         achieved = fl / (per[dom] * 1e-3) / 1e12
         peak = PEAK_TFLOPS[dt_key]
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 5), "traffic": None, "avg_launch_ms": round(per[dom], 4),
+                "frac": round(achieved / peak, 5), "traffic": pmc_traffic(dom, args.precision), "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
+                "avg_launch_ms": round(per[dom], 4),
                 "alg_flops_per_launch": fl, "kernels_ms": {k: round(v, 4) for k, v in sorted(per.items())}}
     barrier()
 
@@ -203,6 +227,23 @@ def main():
             "final_stats": {"loss": stats[0], "recon": stats[1], "kl": stats[2], "grad_norm": stats[3]},
             "roofline": roof,
         }
+        if world == 1 and args.precision == "bf16" and not args.no_fp32_leg:
+            # the fp32 parity path (recon/mu/logvar within 1e-4 of the reference) on the same workload, same run
+            del trainer
+            torch.manual_seed(42)
+            m32 = TemporalVAE(D, Z, H, L, 0.3, precision="fp32").to(dev).train()
+            tr32 = VAETrainer(m32, lr=1e-3, weight_decay=1e-5, max_norm=2.0, seed=42)
+            for i in range(2):
+                tr32.step(data[i * B_PER_GPU:(i + 1) * B_PER_GPU], KL_W)
+            torch.cuda.synchronize()
+            t32 = time.perf_counter()
+            n32 = 8
+            for i in range(n32):
+                tr32.step(data[(i % n_batches) * B_PER_GPU:((i % n_batches) + 1) * B_PER_GPU], KL_W)
+            torch.cuda.synchronize()
+            d32 = time.perf_counter() - t32
+            out["fp32_parity_path"] = {"value": round(B_PER_GPU * n32 / d32, 2), "unit": "windows/s", "ms_per_step": round(1e3 * d32 / n32, 4),
+                                       "steps": n32, "dtype": "f32", "whole_step_mfma_frac": round(B_PER_GPU * n32 / d32 * step_flops / (PEAK_TFLOPS["f32"] * 1e12), 5)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
