@@ -1,0 +1,39 @@
+"""Hybrid inference on MI355X — counterpart of reference 4DOF/Scripts/06_test_full_pipeline.py (gate -> CNN; sklearn reporting omitted).
+    python -m Scripts.06_test_full_pipeline --root /path/to/4DOF"""
+import argparse
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+_PKG = Path(__file__).resolve().parent.parent
+if str(_PKG) not in sys.path:
+    sys.path.insert(0, str(_PKG))
+
+from Scripts.Models.cnn_model import CNN, NUM_FEATURES, SEQ_LEN   # noqa: E402
+from Scripts.Models.temporal_vae import TemporalVAE                # noqa: E402
+from shm_hip import dataprep, workflows                           # noqa: E402
+
+TEST_FRAC = (0.7, 1.0)
+
+
+def main():
+    ap = argparse.ArgumentParser(); ap.add_argument("--root", required=True); a = ap.parse_args()
+    root = Path(a.root)
+    splits = json.loads((root / "Data/processed/run_splits.json").read_text())
+    st = np.load(root / "Data/processed/normal_stats.npz")
+    thr = float(json.loads((root / "Data/processed/vae_threshold.json").read_text())["threshold"])
+    vae = TemporalVAE(NUM_FEATURES, 16, 128, 2, 0.3).to("cuda")
+    vae.load_state_dict(torch.load(root / "models/temporal_vae_state_dict.pt", map_location="cuda"))
+    cnn = CNN(2, 2, 0.5).to("cuda")
+    cnn.load_state_dict(torch.load(root / "models/cnn_state_dict.pt", map_location="cuda"))
+    groups = {name: dataprep.normalize_windows(dataprep.fraction_windows(splits[key]["files"], TEST_FRAC, SEQ_LEN, NUM_FEATURES, 1, root), st["mean"], st["std"])
+              for name, key in (("normal", "normal"), ("sensor", "sensor_fault"), ("structural", "structural_fault"))}
+    conf, gate = workflows.test_pipeline(vae, cnn, groups, thr)
+    print(json.dumps(dict(confusion=conf.tolist(), gate=gate), indent=2))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,83 @@
+"""Host-side data preparation shared by every stage.
+
+Semantics follow reference 4DOF/Scripts/03_train_vae.py:81-117 (duplicated there in 04:73-110, 05:76-115, 06:91-126):
+CSV (one header row) -> fp32 rows; fraction slice with int(n*f); stride-1 windows; per-channel mean/std over all window rows
+with std == 0 -> 1e-6; z-score with NaN/inf -> 0.  numpy only; the windows go to the device once, as one tensor.
+"""
+from __future__ import annotations
+
+from pathlib import Path
+
+import numpy as np
+
+
+def load_csv_numeric(path, num_features: int) -> np.ndarray:
+    path = Path(path)
+    if not path.exists():
+        raise FileNotFoundError(f"Missing CSV: {path}")
+    X = np.loadtxt(str(path), delimiter=",", skiprows=1, dtype=np.float64, ndmin=2).astype(np.float32)
+    if X.ndim != 2 or X.shape[1] != num_features:
+        raise ValueError(f"Bad CSV shape in {path}: {X.shape}")
+    return X
+
+
+def slice_frac(X: np.ndarray, frac_range) -> np.ndarray:
+    n = X.shape[0]
+    lo, hi = int(n * float(frac_range[0])), int(n * float(frac_range[1]))
+    return X[lo:max(hi, lo)]
+
+
+def make_windows(X: np.ndarray, win_len: int, stride: int = 1) -> np.ndarray:
+    n = X.shape[0] - win_len + 1
+    if n <= 0:
+        return np.zeros((0, win_len, X.shape[1]), dtype=np.float32)
+    starts = np.arange(0, n, stride)
+    # one strided view + one copy instead of a Python loop over windows
+    view = np.lib.stride_tricks.sliding_window_view(X, win_len, axis=0)      # [n, D, win_len]
+    return np.ascontiguousarray(view[starts].transpose(0, 2, 1), dtype=np.float32)
+
+
+def mean_std_from_windows(W: np.ndarray):
+    if W.shape[0] == 0:
+        raise RuntimeError("No training windows available to compute mean/std.")
+    flat = W.reshape(-1, W.shape[-1])
+    mean = flat.mean(axis=0).astype(np.float32)
+    std = flat.std(axis=0).astype(np.float32)
+    std[std == 0] = 1e-6
+    return mean, std
+
+
+def normalize_windows(W: np.ndarray, mean: np.ndarray, std: np.ndarray) -> np.ndarray:
+    Z = (W - mean[None, None, :]) / std[None, None, :]
+    return np.nan_to_num(Z, nan=0.0, posinf=0.0, neginf=0.0).astype(np.float32)
+
+
+def fraction_windows(files, frac, win_len: int, num_features: int, stride: int = 1, root=None) -> np.ndarray:
+    """All windows of the time-fraction `frac` of every file (03_train_vae.py:165-175)."""
+    out = []
+    for fp in files:
+        p = Path(fp)
+        if not p.is_absolute() and root is not None:
+            p = (Path(root) / p).resolve()
+        W = make_windows(slice_frac(load_csv_numeric(p, num_features), frac), win_len, stride)
+        if W.shape[0]:
+            out.append(W)
+    if not out:
+        return np.zeros((0, win_len, num_features), dtype=np.float32)
+    return np.concatenate(out, axis=0).astype(np.float32)
+
+
+def windows_by_index(files, window_indices, split: str, win_len: int, num_features: int, root=None):
+    """Windows selected by run_splits.json's per-file start indices (05_train_cnn.py:209-213)."""
+    out = []
+    for fp in files:
+        p = Path(fp)
+        if not p.is_absolute() and root is not None:
+            p = (Path(root) / p).resolve()
+        X = load_csv_numeric(p, num_features)
+        idx = window_indices[fp][split]
+        if len(idx):
+            out.append(np.stack([X[i:i + win_len] for i in idx], axis=0).astype(np.float32))
+    if not out:
+        return np.zeros((0, win_len, num_features), dtype=np.float32)
+    return np.concatenate(out, axis=0)

@@ -1,0 +1,106 @@
+"""End-to-end stages 03 -> 04 -> 05 -> 06 on a synthetic 4DOF-like data root (GPU).
+
+The reference's own data (CSV runs) cannot travel; the synthetic root has the same layout (Data/processed/run_splits.json,
+mode window_level_per_file) and three signal families: normal (sum of sines), sensor fault (additive bias/spikes on some
+channels), structural fault (frequency shift).  Checks are behavioural: loss falls, the P99 gate fires on faults, the CNN
+separates the two fault kinds, artifacts exist with the reference's names.
+"""
+import json
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import PKG
+
+pytestmark = pytest.mark.gpu
+T, D = 100, 12
+
+
+def _signal(n, rng, kind):
+    t = np.arange(n)[:, None] * 0.02
+    f = np.linspace(1.0, 4.0, D)[None, :] * (1.35 if kind == "structural" else 1.0)
+    x = np.sin(2 * np.pi * f * t + rng.uniform(0, 6.28, (1, D))) + 0.05 * rng.standard_normal((n, D))
+    if kind == "sensor":
+        x[:, :4] += 2.5 + 0.5 * rng.standard_normal((n, 4))
+    return x.astype(np.float32)
+
+
+@pytest.fixture(scope="module")
+def root(tmp_path_factory):
+    root = tmp_path_factory.mktemp("dof4")
+    rng = np.random.default_rng(7)
+    (root / "Data/raw").mkdir(parents=True); (root / "Data/processed").mkdir(parents=True)
+    splits = {"mode": "window_level_per_file"}
+    for key, kind in (("normal", "normal"), ("sensor_fault", "sensor"), ("structural_fault", "structural")):
+        files, widx = [], {}
+        for k in range(2):
+            n = 900
+            rel = f"Data/raw/{kind}_{k}.csv"
+            np.savetxt(root / rel, _signal(n, rng, kind), delimiter=",", header=",".join(f"c{i}" for i in range(D)), comments="")
+            files.append(rel)
+            starts = rng.permutation(n - T + 1)
+            widx[rel] = {"train": sorted(starts[:200].tolist()), "val": sorted(starts[200:280].tolist()), "test": sorted(starts[280:360].tolist())}
+        splits[key] = {"files": files, "window_indices": widx}
+    (root / "Data/processed/run_splits.json").write_text(json.dumps(splits))
+    return root
+
+
+def test_stages_end_to_end(root):
+    from shm_hip import dataprep, workflows
+    splits = json.loads((root / "Data/processed/run_splits.json").read_text())
+    nf = splits["normal"]["files"]
+    Wtr = dataprep.fraction_windows(nf, (0.0, 0.4), T, D, 1, root)
+    Wva = dataprep.fraction_windows(nf, (0.4, 0.7), T, D, 1, root)
+    assert Wtr.shape == (2 * (360 - T + 1), T, D)
+    mean, std = dataprep.mean_std_from_windows(Wtr)
+    np.savez(root / "Data/processed/normal_stats.npz", mean=mean, std=std)
+    Ztr, Zva = dataprep.normalize_windows(Wtr, mean, std), dataprep.normalize_windows(Wva, mean, std)
+
+    logs = []
+    vae, hist = workflows.train_vae(Ztr, Zva, root / "models", epochs=6, batch_size=64, log=logs.append)
+    assert len(hist["epoch"]) == 6 and len(logs) == 12
+    assert hist["kl_w"][0] == pytest.approx(1e-4) and hist["kl_w"][-1] == pytest.approx(1e-2)
+    assert hist["train_recon"][-1] < 0.7 * hist["train_recon"][0]
+    assert np.isfinite(hist["val_total"]).all()
+    meta = json.loads((root / "models/stage1_vae_train_meta.json").read_text())
+    assert meta["best_epoch"] >= 1 and (root / "models/temporal_vae_state_dict.pt").exists()
+    # the saved state dict has the reference's key names and reloads into a fresh module
+    sd = torch.load(root / "models/temporal_vae_state_dict.pt", map_location="cuda", weights_only=True)
+    assert "enc_lstm.weight_ih_l0" in sd and "dec_out.bias" in sd
+    from Scripts.Models.temporal_vae import TemporalVAE
+    vae2 = TemporalVAE(D, 16, 128, 2, 0.3).to("cuda"); vae2.load_state_dict(sd)
+
+    thr, scores = workflows.vae_threshold(vae2, Zva, root / "Data/processed")
+    tj = json.loads((root / "Data/processed/vae_threshold.json").read_text())
+    assert tj["threshold"] == pytest.approx(thr) and thr == pytest.approx(float(np.percentile(scores, 99.0)))
+
+    data = {}
+    for split in ("train", "val"):
+        Ws = dataprep.windows_by_index(splits["sensor_fault"]["files"], splits["sensor_fault"]["window_indices"], split, T, D, root)
+        Wt = dataprep.windows_by_index(splits["structural_fault"]["files"], splits["structural_fault"]["window_indices"], split, T, D, root)
+        Z = dataprep.normalize_windows(np.concatenate([Ws, Wt]), mean, std)
+        y = np.concatenate([np.zeros(len(Ws), np.int64), np.ones(len(Wt), np.int64)])
+        data[split] = (workflows.build_cnn_inputs(vae2, Z), y)
+    assert data["train"][0].shape == (800, 2, T, D)
+    cnn, chist = workflows.train_cnn(*data["train"], *data["val"], root / "models", epochs=8, batch_size=100, lr=1e-3, log=logs.append)
+    assert chist[-1][1] < chist[0][1] and (root / "models/cnn_state_dict.pt").exists()
+
+    groups = {name: dataprep.normalize_windows(dataprep.fraction_windows(splits[key]["files"], (0.7, 1.0), T, D, 1, root), mean, std)
+              for name, key in (("normal", "normal"), ("sensor", "sensor_fault"), ("structural", "structural_fault"))}
+    conf, gate = workflows.test_pipeline(vae2, cnn, groups, thr)
+    assert conf.sum(1).tolist() == [g.shape[0] for g in groups.values()]
+    assert gate["sensor"]["anom_rate"] > 0.9 and gate["structural"]["anom_rate"] > 0.9 and gate["normal"]["anom_rate"] < 0.3
+    assert conf[1, 1] > 0.8 * conf[1].sum() and conf[2, 2] > 0.8 * conf[2].sum()
+
+
+def test_numbered_scripts_run(root):
+    """The CLI counterparts (03 -> 04 -> 06 needs 05's model: run all four, tiny epoch counts) exit 0 and leave the artifacts."""
+    for mod, extra in (("Scripts.03_train_vae", ["--epochs", "2"]), ("Scripts.04_vae_thresholding", []),
+                       ("Scripts.05_train_cnn", ["--epochs", "2"]), ("Scripts.06_test_full_pipeline", [])):
+        r = subprocess.run([sys.executable, "-m", mod, "--root", str(root), *extra], cwd=str(PKG), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+    assert (root / "Data/processed/vae_mean.npy").exists() and (root / "Data/processed/vae_threshold.json").exists()
+    assert '"confusion"' in r.stdout

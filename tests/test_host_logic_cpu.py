@@ -1,0 +1,43 @@
+"""CPU tests of the host-side rows: KL schedules (a7) and data preparation (a9) against the reference goldens."""
+import numpy as np
+
+from conftest import load_golden
+from shm_hip import dataprep, schedules
+
+
+def test_kl_schedules_match_reference():
+    g = load_golden("kl_weight")
+    assert np.allclose([schedules.kl_weight_4dof(e, 50, 0.30) for e in range(1, 51)], g["dof4"], rtol=0, atol=1e-15)
+    assert np.allclose([schedules.kl_weight_1dof(e, 100) for e in range(100)], g["dof1"], rtol=0, atol=1e-15)
+    assert np.allclose([schedules.kl_weight_openlab(e, 100) for e in range(1, 101)], g["openlab"], rtol=0, atol=1e-15)
+
+
+def test_dataprep_matches_reference_on_the_shipped_csv_head(tmp_path):
+    g = load_golden("dataprep")
+    raw = g["raw_head"]                                            # first 140 rows of 4DOF/Data/raw/normal/normal_seed2025.csv
+    csv = tmp_path / "run.csv"
+    np.savetxt(csv, raw, delimiter=",", header=",".join(f"c{i}" for i in range(12)), comments="", fmt="%.9g")
+    X = dataprep.load_csv_numeric(csv, 12)
+    assert X.dtype == np.float32 and np.array_equal(X, raw)
+    W = dataprep.make_windows(X, 100, 1)
+    assert W.shape == (41, 100, 12) and W.dtype == np.float32
+    assert np.array_equal(W[0], g["win_first"])                    # window 0 of the reference's first normal run
+    assert np.array_equal(W[7], raw[7:107])
+    Z = dataprep.normalize_windows(W[:4], g["mean"], g["std"])
+    assert np.array_equal(Z, g["z4"])                              # bit-identical to the reference's normalisation
+    # slice_frac: int(n * f) on both ends, as on the 1001-row runs (0.0-0.4 -> 400 rows -> 301 windows)
+    full = np.zeros((int(g["n_rows"]), 12), np.float32)
+    assert dataprep.slice_frac(full, (0.0, 0.4)).shape[0] == int(g["slice_rows"])
+    assert dataprep.make_windows(dataprep.slice_frac(full, (0.0, 0.4)), 100, 1).shape[0] == int(g["n_win0"])
+    assert dataprep.make_windows(full[:50], 100, 1).shape == (0, 100, 12)
+
+
+def test_mean_std_rules():
+    W = np.random.default_rng(0).standard_normal((5, 7, 3)).astype(np.float32)
+    W[:, :, 2] = 4.0                                               # constant channel -> std 0 -> 1e-6
+    mean, std = dataprep.mean_std_from_windows(W)
+    assert np.allclose(mean, W.reshape(-1, 3).mean(0)) and std[2] == np.float32(1e-6)
+    Z = dataprep.normalize_windows(W, mean, std)
+    assert np.isfinite(Z).all()
+    bad = W.copy(); bad[0, 0, 0] = np.nan; bad[0, 1, 1] = np.inf
+    assert np.isfinite(dataprep.normalize_windows(bad, mean, std)).all()
