@@ -41,9 +41,13 @@ def kernel_alg_flops(name, B, bf16=False):
     G = 4 * H
     kind, _, inst = name.partition(".")
     if kind == "lstm_fwd":
+        if inst in ("enc", "dec"):                                          # layer-pipelined launch: both layers of the stack
+            return kernel_alg_flops(f"lstm_fwd.{inst}0", B, bf16) + kernel_alg_flops(f"lstm_fwd.{inst}1", B, bf16)
         k_in = {"enc0": D, "enc1": H, "dec0": 0, "dec1": H}[inst]          # dec0: constant input, projected once
         return B * T * 2 * G * (k_in + H) + (B * 2 * G * H if inst == "dec0" else 0)
     if kind == "lstm_bwd":
+        if inst in ("enc", "dec"):                                          # layer-pipelined launch incl. the dx product
+            return 2 * B * T * 2 * G * H + B * T * 2 * G * H
         k_dx = 0 if bf16 else {"enc0": 0, "enc1": H, "dec0": 0, "dec1": H}[inst]   # dx only for layers with a layer below
         return B * T * 2 * G * (H + k_dx)
     if kind == "dx_gemm":

@@ -3,6 +3,7 @@
 // The launch sequence mirrors TemporalVAE.forward (reference 4DOF/Scripts/Models/temporal_vae.py:72-77) and the
 // train step of 4DOF/Scripts/03_train_vae.py:262-271; each stage is one persistent kernel per LSTM layer.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -61,6 +62,7 @@ struct shm_vae_plan {
     size_t recon, score, d_recon, d_mu, d_lv, dpre_seq, dx_seq, dpre_tsum, gemm_partial, colsum_scratch;
     size_t gemm_partial_elems;
     size_t narrow_scratch;  // block partials of narrow_tn
+    size_t pair_sync;       // bf16 path, 2 layers: ticket / error / progress words of the layer-pipelined launches
     size_t params_copy;     // flat fp32 copy of the parameters (head / output layer read them unpacked)
     size_t ws_bytes;
     // call-order state
@@ -115,6 +117,14 @@ static int build_layout(const shm_vae_config* c, std::vector<shm_tensor_desc>& o
     lstm("decoder_lstm", H);
     add("output_layer.weight", 2, D, H); add("output_layer.bias", 1, D, 0);
     return (int)off;
+}
+
+// Layer-pipelined launches can be switched off (one launch per layer) for A/B measurements and for the bit-identity test:
+// SHM_PAIR_LAUNCH=0 in the environment, or shm_set_pair_launch(0).  Results are bit-identical either way.
+static int g_pair_launch = -1;
+static bool pair_launch_enabled() {
+    if (g_pair_launch < 0) { const char* e = getenv("SHM_PAIR_LAUNCH"); g_pair_launch = (e && e[0] == '0') ? 0 : 1; }
+    return g_pair_launch != 0;
 }
 
 template <typename T>
@@ -228,6 +238,7 @@ extern "C" int shm_vae_plan_create(const shm_vae_config* cfg, int32_t B, int32_t
             }
         }
     }
+    if (bf && L == 2) p->pair_sync = take_bytes(lstm_fwd_pair_sync_bytes(B) + 64);   // + the sticky error word
     p->params_copy = take((size_t)p->n_params);
     p->h_last = take((size_t)B * H); p->eps = take((size_t)B * Z);
     p->y = take((size_t)B * H); p->xhat = take((size_t)B * H); p->rstd = take(B);
@@ -277,6 +288,7 @@ extern "C" int shm_vae_pack_weights(shm_vae_plan* p, const float* params, void* 
     hipStream_t s = (hipStream_t)stream;
     const int H = p->cfg.hidden_dim, L = p->cfg.num_layers;
     SHM_HIP_CHECK(hipMemcpyAsync(at<float>(ws, p->params_copy), params, sizeof(float) * p->n_params, hipMemcpyDeviceToDevice, s));
+    if (p->pair_sync) SHM_HIP_CHECK(hipMemsetAsync(at<char>(ws, p->pair_sync + lstm_fwd_pair_sync_bytes(p->B)), 0, 64, s));
     if (p->cfg.precision == SHM_PREC_BF16) {          // bf16 path: every re-layout in one launch
         PackJobs jobs;
         jobs.n = 0;
@@ -341,21 +353,32 @@ extern "C" int shm_vae_forward(shm_vae_plan* p, const float* x, const float* eps
     SHM_HIP_CHECK(hipMemcpyAsync(at<float>(ws, p->eps), eps, sizeof(float) * B * Z, hipMemcpyDeviceToDevice, s));
 
     auto run_stack = [&](LayerInst* st, const float* in0, uint32_t stack, float* h_last) -> int {
+        auto fwd_args = [&](int l) {
+            LstmFwdArgsB a;
+            memset(&a, 0, sizeof(a));
+            a.in = l == 0 ? (const void*)in0 : (const void*)at<bf16_t>(ws, st[l - 1].h_seq);
+            a.in_f32 = l == 0 ? 1 : 0;
+            a.Wx = at<bf16_t>(ws, st[l].Wx); a.Wh = at<bf16_t>(ws, st[l].Wh); a.bias = at<float>(ws, st[l].bsum);
+            a.h_seq = at<bf16_t>(ws, st[l].h_seq);
+            a.h_last = (l == L - 1) ? h_last : nullptr;
+            a.sv_g = save ? at<bf16_t>(ws, st[l].saved) : nullptr;
+            a.xdrop = (l > 0 && c.dropout > 0.f) ? at<bf16_t>(ws, st[l].xdrop) : nullptr;
+            a.B = B; a.T = T; a.In = st[l].In; a.in_const = st[l].in_const ? 1 : 0;
+            a.drop_p = l > 0 ? drop : 0.f; a.drop_seed = drop_seed; a.drop_stack = stack;
+            return a;
+        };
+        if (c.precision == SHM_PREC_BF16 && L == 2 && pair_launch_enabled()) {   // both layers in one launch, layer 1 a few steps behind
+            LstmFwdPairArgsB pa;
+            pa.l0 = fwd_args(0); pa.l1 = fwd_args(1); pa.sync = at<unsigned>(ws, p->pair_sync); pa.role_lds_off = 0;
+            pa.err = at<unsigned>(ws, p->pair_sync + lstm_fwd_pair_sync_bytes(B));
+            KernelTimer kt(stack == 0 ? "lstm_fwd.enc" : "lstm_fwd.dec", s);
+            return launch_lstm_fwd_pair_bf16(H, pa, s);
+        }
         for (int l = 0; l < L; ++l) {
             char nm[32];
             snprintf(nm, sizeof(nm), "lstm_fwd.%s%d", stack == 0 ? "enc" : "dec", l);
             if (c.precision == SHM_PREC_BF16) {
-                LstmFwdArgsB a;
-                memset(&a, 0, sizeof(a));
-                a.in = l == 0 ? (const void*)in0 : (const void*)at<bf16_t>(ws, st[l - 1].h_seq);
-                a.in_f32 = l == 0 ? 1 : 0;
-                a.Wx = at<bf16_t>(ws, st[l].Wx); a.Wh = at<bf16_t>(ws, st[l].Wh); a.bias = at<float>(ws, st[l].bsum);
-                a.h_seq = at<bf16_t>(ws, st[l].h_seq);
-                a.h_last = (l == L - 1) ? h_last : nullptr;
-                a.sv_g = save ? at<bf16_t>(ws, st[l].saved) : nullptr;
-                a.xdrop = (l > 0 && c.dropout > 0.f) ? at<bf16_t>(ws, st[l].xdrop) : nullptr;
-                a.B = B; a.T = T; a.In = st[l].In; a.in_const = st[l].in_const ? 1 : 0;
-                a.drop_p = l > 0 ? drop : 0.f; a.drop_seed = drop_seed; a.drop_stack = stack;
+                const LstmFwdArgsB a = fwd_args(l);
                 KernelTimer kt(nm, s);
                 int r = launch_lstm_fwd_bf16(H, a, s);
                 if (r) return r;
@@ -393,6 +416,25 @@ extern "C" int shm_vae_forward(shm_vae_plan* p, const float* x, const float* eps
     if (score) SHM_HIP_CHECK(hipMemcpyAsync(score, at<float>(ws, p->score), sizeof(float) * B, hipMemcpyDeviceToDevice, s));
     p->recon_ptr = rec;
     p->fwd_saved = save;
+    return SHM_OK;
+}
+
+extern "C" int shm_set_pair_launch(int on) {
+    const int prev = pair_launch_enabled() ? 1 : 0;
+    g_pair_launch = on ? 1 : 0;
+    return prev;
+}
+
+extern "C" int shm_vae_plan_status(const shm_vae_plan* p, const void* ws, void* stream) {
+    int rc = check_ws(p, ws);
+    if (rc) return rc;
+    if (!p->pair_sync) return SHM_OK;
+    unsigned word = 0;
+    SHM_HIP_CHECK(hipMemcpyAsync(&word, reinterpret_cast<const char*>(ws) + p->pair_sync + lstm_fwd_pair_sync_bytes(p->B), 4,
+                                 hipMemcpyDeviceToHost, (hipStream_t)stream));
+    SHM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    SHM_REQUIRE(word == 0, SHM_ESTATE, "layer-pipelined launch: the consumer of tile %u gave up waiting for its producer; results since the last "
+                "shm_vae_pack_weights are invalid", word - 1);
     return SHM_OK;
 }
 

@@ -124,6 +124,10 @@ struct LstmFwdArgsB {
     float drop_p; uint64_t drop_seed; uint32_t drop_stack;
 };
 int launch_lstm_fwd_bf16(int H, const LstmFwdArgsB& a, hipStream_t s);
+// both layers of a 2-layer stack in one launch, layer 1 running a few steps behind layer 0 on its own workgroups
+struct LstmFwdPairArgsB { LstmFwdArgsB l0, l1; unsigned* sync; unsigned* err; int role_lds_off; };   // sync: zeroed per launch; err: sticky
+size_t lstm_fwd_pair_sync_bytes(int B);
+int launch_lstm_fwd_pair_bf16(int H, const LstmFwdPairArgsB& p, hipStream_t s);
 
 struct LstmBwdArgsB {
     const bf16_t* sv_g; const float* sv_c;

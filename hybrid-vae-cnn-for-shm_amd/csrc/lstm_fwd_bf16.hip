@@ -20,6 +20,16 @@
 //     steps peeled, slot use pinned with an empty asm) so the compiler emits one counted s_waitcnt vmcnt per step.
 //     (Issuing W_ih x_{t+1} at the end of step t, ahead of the barrier, was measured SLOWER — 0.29 vs 0.27 ms per layer-1
 //     launch: the two waves of a SIMD share its MFMA pipe, so the extra MFMAs only delay the barrier arrival.)
+//
+// Layer pipelining (lstm_fwd_pair_bf16_kernel): a 2-layer stack runs as ONE launch of 2 x tiles workgroups.  Layer 1 of
+// tile i consumes h^0_t of tile i a few steps behind the layer-0 workgroup that produces it, so both layers' recurrences
+// overlap on 2 x 128 CUs instead of running back to back on 128.  The hand-off is the sc1 form of the CDNA4 guide
+// (cdna_hip_programming.md §6 Guideline 16, R1): every h_seq byte is stored write-through (buffer_store ... sc1) by wave 0,
+// which retires the stores of step t-DLY with a COUNTED s_waitcnt (vmcnt completes in order, so waiting until at most
+// (DLY-1) x ops-per-step are outstanding retires everything DLY steps old) and then publishes "steps < n are in memory"
+// with one sc1 flag store; the consumer polls that word with sc1 loads and reads h_seq ONLY with sc1 buffer loads.
+// Roles come from a ticket (atomicAdd), not from blockIdx: a consumer only ever waits for a workgroup that drew a smaller
+// ticket, i.e. one that is already running, so the launch cannot deadlock whatever the dispatch order or residency.
 #include "kernels.hpp"
 
 namespace shm {
@@ -27,11 +37,22 @@ namespace shm {
 namespace {
 
 constexpr int WPT = SHM_WPT;     // windows per workgroup
+constexpr int DLY = 4;           // pair launch: a step's h_seq rows are published DLY steps after they were stored
+constexpr unsigned SPIN_MAX = 1u << 21;   // bounded consumer spin (a safety net: ~1 s); on expiry the err word is set
+
+typedef __attribute__((address_space(1))) unsigned gu32;
+#define SHM_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
 
 // XK: k-steps (of 32) of the input operand.  XF32: dynamic input is fp32 [B,T,In] with In <= 16 (encoder layer 0).
 // CONSTIN: the input is one fp32 vector per window (decoder layer 0).  SAVE: keep the BPTT records.
-template <int H, int XK, bool XF32, bool DROP, bool CONSTIN, bool SAVE>
-__global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
+// CONSUME: the input sequence is being produced by another workgroup of this launch (flag_in).  PRODUCE: h_seq is
+// consumed by another workgroup of this launch (flag_out).
+template <int H, int XK, bool XF32, bool DROP, bool CONSTIN, bool SAVE, bool CONSUME, bool PRODUCE>
+__device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int tile, gu32* flag_in, gu32* flag_out, gu32* err) {
+    static_assert(!CONSUME || (!XF32 && !CONSTIN), "a consumer reads the bf16 h_seq of the layer below");
     constexpr int NW = H / 16, NTHR = 64 * NW;
     constexpr int KSH = H / 32;                 // k-steps of the recurrent operand
     constexpr int KQH = H / 4, RSH = lds_row_stride(KQH);
@@ -44,7 +65,6 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
 
     const int In = a.In, T = a.T, B = a.B;
     const int tid = threadIdx.x, lane = tid & 63, ht = tid >> 6, q = lane >> 4, j = lane & 15;
-    const int tile = blockIdx.x;
     // cell owned by this lane after the re-deal
     const int cj = j & 3, cr = j >> 2, cu = ht * 16 + q * 4 + cr;      // window within the tile, unit
     const int cb = tile * WPT + cj;
@@ -88,11 +108,35 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
     // XF32 staging: element e < WPT*In of the tile -> (window jj, channel kk); In <= 16 so one element per thread suffices
     const int xe = tid < WPT * In ? tid : 0, xj0 = xe / In, xk0 = xe - xj0 * In;
     const int xb0 = tile * WPT + xj0 < B ? tile * WPT + xj0 : B - 1;
+    // pair launch: the tile's block of the producer's h_seq, read with sc1 (L1-bypassing) buffer loads only
+    const uint32_t seq_bytes = (uint32_t)T * WPT * H * 2;
+    const __amdgpu_buffer_rsrc_t in_rsrc = make_rsrc(CONSUME ? reinterpret_cast<const bf16_t*>(a.in) + (size_t)tile * T * WPT * H : nullptr, CONSUME ? seq_bytes : 0);
+    const __amdgpu_buffer_rsrc_t out_rsrc = make_rsrc(PRODUCE ? a.h_seq + (size_t)tile * T * WPT * H : nullptr, PRODUCE ? seq_bytes : 0);
+    int avail = 0;                                        // wave-uniform: producer steps < avail are in memory
+    auto wait_for = [&](int need) {
+        if (avail >= need) return;
+        unsigned v, spins = 0;
+#pragma clang loop unroll(disable)
+        for (;;) {
+            v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flag_in, SHM_RLX_AGENT));
+            if ((int)v >= need) break;
+            if (++spins > SPIN_MAX) {                      // give up: finish with garbage, flagged in the err word
+                if (lane == 0) __hip_atomic_store(err, 1u + (unsigned)tile, SHM_RLX_AGENT);
+                v = 0x7fffffff;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        avail = (int)v;
+    };
     auto x_fetch = [&](XSlot& X, int t) {
         if constexpr (CONSTIN) return;
         const int tc = t < T ? t : T - 1;                  // clamp: steps >= T are fetched but never committed
         if constexpr (XF32) {
             X.s0 = reinterpret_cast<const float*>(a.in)[((size_t)xb0 * T + tc) * In + xk0];
+        } else if constexpr (CONSUME) {
+            wait_for(tc + 1);
+            X.v = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (uint32_t)(tc * WPT * H + xc * 8) * 2, 0, 16));
         } else {
             X.v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(a.in) + ((size_t)tile * T + tc) * WPT * H + (size_t)xc * 8);
         }
@@ -171,10 +215,22 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
     u32x4* sv = SAVE ? reinterpret_cast<u32x4*>(a.sv_g) + ((size_t)tile * T * NW + ht) * 64 + lane : nullptr;
 
     // h_{t} image -> h_seq block (tile, t): 16-byte chunks, fully coalesced; called once the image is complete (after the barrier)
+    // vector-memory instructions wave 0 issues per step besides the flag store (h_seq, record, x prefetch, masked x)
+    constexpr int OPS = 1 + (SAVE ? 1 : 0) + (CONSTIN ? 0 : 1) + (DROP ? 1 : 0);
     auto h_flush = [&](int t_done, int buf) {
-        if (tid < NCH)
-            *reinterpret_cast<bf16x8*>(a.h_seq + ((size_t)tile * T + t_done) * WPT * H + (size_t)xc * 8) =
-                *reinterpret_cast<const bf16x8*>(h_lds + buf * HBUF + h_img_off);
+        if (tid < NCH) {
+            if constexpr (PRODUCE) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(h_lds + buf * HBUF + h_img_off);
+                __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, (uint32_t)(t_done * WPT * H + xc * 8) * 2, 0, 16);
+                // in-order vmcnt: with at most (DLY-1)*OPS younger operations outstanding, the h_seq store of step
+                // t_done - DLY + 1 ... has retired; publish one step more conservatively than that
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DLY - 1) * OPS) : "memory");
+                if (tid == 0 && t_done >= DLY) __hip_atomic_store(flag_out, (unsigned)(t_done - DLY + 1), SHM_RLX_AGENT);
+            } else {
+                *reinterpret_cast<bf16x8*>(a.h_seq + ((size_t)tile * T + t_done) * WPT * H + (size_t)xc * 8) =
+                    *reinterpret_cast<const bf16x8*>(h_lds + buf * HBUF + h_img_off);
+            }
+        }
     };
     // X: slot holding x_{t+1}; committed at the end of the step and refilled with x_{t+4}
     auto step = [&](XSlot& X, int t) {
@@ -225,7 +281,40 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
         step(X2, t + 2);
     }
     h_flush(T - 1, T & 1);                                 // the last image (buffer T&1; its barrier has passed)
+    if constexpr (PRODUCE) {
+        if (tid < NCH) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (tid == 0) __hip_atomic_store(flag_out, (unsigned)T, SHM_RLX_AGENT);
+        }
+    }
     if (a.h_last && cvalid) a.h_last[(size_t)cb * H + cu] = h;
+}
+
+template <int H, int XK, bool XF32, bool DROP, bool CONSTIN, bool SAVE>
+__global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
+    lstm_fwd_body<H, XK, XF32, DROP, CONSTIN, SAVE, false, false>(a, blockIdx.x, nullptr, nullptr, nullptr);
+}
+
+// Two layers, one launch.  sync: [0] ticket, flag of tile i at sync[16 * (1 + i)] (a 64-byte line each), zeroed by the
+// launcher's memset before every launch; err: a sticky word outside that block.
+template <int H, bool XF32_0, bool DROP, bool SAVE>
+__global__ void __launch_bounds__(4 * H) lstm_fwd_pair_bf16_kernel(LstmFwdPairArgsB p) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem_b[];
+    gu32* sync = (gu32*)p.sync;
+    const int tiles = gridDim.x >> 1;
+    // the ticket word lives at the end of the dynamic LDS region (a static __shared__ would misalign the images)
+    int* role_lds = reinterpret_cast<int*>(reinterpret_cast<char*>(smem_b) + p.role_lds_off);
+    if (threadIdx.x == 0) *role_lds = (int)__hip_atomic_fetch_add(sync, 1u, SHM_RLX_AGENT);
+    __syncthreads();
+    const int role = *role_lds;
+    __syncthreads();
+    if (role < tiles) {
+        if constexpr (XF32_0) lstm_fwd_body<H, 1, true, false, false, SAVE, false, true>(p.l0, role, nullptr, sync + 16 * (1 + role), (gu32*)p.err);
+        else lstm_fwd_body<H, H / 32, false, false, true, SAVE, false, true>(p.l0, role, nullptr, sync + 16 * (1 + role), (gu32*)p.err);
+    } else {
+        const int tile = role - tiles;
+        lstm_fwd_body<H, H / 32, false, DROP, false, SAVE, true, false>(p.l1, tile, sync + 16 * (1 + tile), nullptr, (gu32*)p.err);
+    }
 }
 
 template <int H, int XK, bool XF32, bool CONSTIN>
@@ -258,6 +347,48 @@ int launch_h(const LstmFwdArgsB& a, hipStream_t s) {
 }
 
 }  // namespace
+
+namespace {
+template <int H>
+int launch_pair_h(const LstmFwdPairArgsB& p0, hipStream_t s) {
+    LstmFwdPairArgsB p = p0;
+    const LstmFwdArgsB &a = p.l0, &b = p.l1;
+    SHM_REQUIRE(a.h_seq && b.h_seq && p.sync && p.err, SHM_EINVAL, "lstm_fwd_pair: h_seq or sync is NULL");
+    SHM_REQUIRE(b.in == (const void*)a.h_seq && !b.in_f32 && !b.in_const && b.In == H, SHM_EINVAL, "lstm_fwd_pair: layer 1 must read layer 0's h_seq");
+    SHM_REQUIRE(a.B == b.B && a.T == b.T, SHM_EINVAL, "lstm_fwd_pair: shape mismatch");
+    SHM_REQUIRE((a.sv_g != nullptr) == (b.sv_g != nullptr), SHM_EINVAL, "lstm_fwd_pair: both layers save or neither");
+    SHM_REQUIRE((int64_t)a.T * WPT * H * 2 < ((int64_t)1 << 31), SHM_EINVAL, "lstm_fwd_pair: T too long for 32-bit buffer offsets");
+    const bool xf32 = a.in_f32 && !a.in_const;
+    if (xf32) SHM_REQUIRE(a.In <= 16, SHM_EINVAL, "lstm_fwd_pair: fp32 input width %d too wide (<= 16)", a.In);
+    else SHM_REQUIRE(a.in_const && a.In == H, SHM_EINVAL, "lstm_fwd_pair: layer 0 must be the fp32 input or the constant-input layer");
+    const bool drop = b.drop_p > 0.f, save = a.sv_g != nullptr;
+    SHM_REQUIRE(!drop || b.xdrop, SHM_EINVAL, "lstm_fwd_pair: dropout needs the xdrop buffer");
+    const int tiles = ceil_div(a.B, WPT);
+    const size_t lds = sizeof(bf16_t) * 2 * 4 * 16 * (lds_row_stride(H / 4) + lds_row_stride(H / 4)) + sizeof(float) * (H / 16) * 256;
+    p.role_lds_off = (int)lds;
+    SHM_HIP_CHECK(hipMemsetAsync(p.sync, 0, lstm_fwd_pair_sync_bytes(a.B), s));
+    void (*kern)(LstmFwdPairArgsB);
+    if (xf32) kern = drop ? (save ? lstm_fwd_pair_bf16_kernel<H, true, true, true> : lstm_fwd_pair_bf16_kernel<H, true, true, false>)
+                          : (save ? lstm_fwd_pair_bf16_kernel<H, true, false, true> : lstm_fwd_pair_bf16_kernel<H, true, false, false>);
+    else kern = drop ? (save ? lstm_fwd_pair_bf16_kernel<H, false, true, true> : lstm_fwd_pair_bf16_kernel<H, false, true, false>)
+                     : (save ? lstm_fwd_pair_bf16_kernel<H, false, false, true> : lstm_fwd_pair_bf16_kernel<H, false, false, false>);
+    hipLaunchKernelGGL(kern, dim3(2 * tiles), dim3(4 * H), lds + 16, s, p);
+    SHM_LAUNCH_CHECK();
+    return SHM_OK;
+}
+}  // namespace
+
+size_t lstm_fwd_pair_sync_bytes(int B) { return (size_t)64 * (1 + ceil_div(B, WPT)); }
+
+int launch_lstm_fwd_pair_bf16(int H, const LstmFwdPairArgsB& p, hipStream_t s) {
+    SHM_REQUIRE(p.l0.B > 0 && p.l0.T > 0 && p.l0.In > 0, SHM_EINVAL, "lstm_fwd_pair: empty shape");
+    switch (H) {
+        case 32: return launch_pair_h<32>(p, s);
+        case 64: return launch_pair_h<64>(p, s);
+        case 128: return launch_pair_h<128>(p, s);
+        default: set_error("lstm_fwd_pair: hidden_dim %d unsupported (32, 64, 128)", H); return SHM_EINVAL;
+    }
+}
 
 int launch_lstm_fwd_bf16(int H, const LstmFwdArgsB& a, hipStream_t s) {
     SHM_REQUIRE(a.B > 0 && a.T > 0 && a.In > 0, SHM_EINVAL, "lstm_fwd_bf16: empty shape");

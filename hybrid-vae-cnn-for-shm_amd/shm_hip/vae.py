@@ -139,6 +139,11 @@ class VAEEngine:
         check(lib.shm_vae_backward(pl.handle, _ptr(x), _ptr(d_recon), _ptr(d_mu), _ptr(d_lv), _ptr(grads), _ptr(pl.ws),
                                    _stream()), "shm_vae_backward")
 
+    def check_status(self):
+        """Raises if a layer-pipelined launch of any plan reported a hand-off timeout (synchronises the stream)."""
+        for pl in self._plans.values():
+            check(lib.shm_vae_plan_status(pl.handle, _ptr(pl.ws), _stream()), "shm_vae_plan_status")
+
     def split(self, flat):
         return [flat[off:off + int(torch.Size(shape).numel())].view(shape) for _, off, shape in self.layout]
 

@@ -81,6 +81,15 @@ int  shm_vae_forward(shm_vae_plan* plan, const float* x, const float* eps,
                      float* recon, float* mu, float* logvar, float* score,
                      int32_t train_mode, uint64_t drop_seed, void* workspace, void* stream);
 
+/* Health of the layer-pipelined launches (bf16 path, 2 layers: both LSTM layers of a stack run in ONE launch, the upper
+ * layer consuming the lower layer's h_t a few steps behind through in-launch flags).  Synchronises the stream.  SHM_OK, or
+ * SHM_ESTATE if a consumer workgroup ever gave up waiting (results since the last shm_vae_pack_weights are then invalid).
+ * No reference counterpart: nn.LSTM (temporal_vae.py:32,44) hides its layer loop. */
+int  shm_vae_plan_status(const shm_vae_plan* plan, const void* workspace, void* stream);
+/* Measurement / test knob: 0 = one launch per LSTM layer, 1 = layer-pipelined launches (default; also SHM_PAIR_LAUNCH=0 in
+ * the environment).  Returns the previous setting.  Both settings give bit-identical results. */
+int  shm_set_pair_launch(int on);
+
 /* Loss of 03_train_vae.py:264-266: recon = mean((recon-x)^2), kl = -0.5*mean(1+lv-mu^2-exp(lv)),
  * loss = recon + kl_w*kl.  Writes losses[0..2] = {loss, recon, kl} (device, fp32) and leaves
  * dLoss/d(recon,mu,logvar) in the workspace for shm_vae_backward(..., NULL, NULL, NULL, ...). */

@@ -135,3 +135,42 @@ def test_bf16_train_mode_dropout_matches_oracle_with_same_masks():
     rep = {k: float(np.linalg.norm(got[k].cpu().numpy().astype(np.float64) - v) / max(np.linalg.norm(v), 1e-12)) for k, v in grads.items()}
     print("bf16 dropout grad rel-L2 max", max(rep.values()))
     assert max(rep.values()) < 2e-2, rep
+
+
+@pytest.mark.parametrize("train_mode", [False, True])
+def test_bf16_layer_pipelined_launch_is_bit_identical(train_mode):
+    """2-layer stacks run as ONE launch (layer 1 consuming layer 0's h_t through in-launch sc1 hand-offs).  The schedule must
+    not change a bit: compare against one launch per layer, repeatedly (a stale or early read would show up as a mismatch),
+    at the north-star shape, with a ragged last tile (B = 510) and with T not a multiple of 3."""
+    from Scripts.Models.temporal_vae import TemporalVAE
+    from shm_hip._capi import lib
+    from shm_hip.trainer import VAETrainer
+    for (B, T, H) in ((512, 256, 128), (510, 100, 128), (37, 50, 64), (9, 31, 32)):
+        torch.manual_seed(11)
+        m = TemporalVAE(4, 16, H, 2, 0.3, precision="bf16").cuda()
+        gen = torch.Generator().manual_seed(B)
+        x = torch.randn(B, T, 4, generator=gen).cuda()
+        eps = torch.randn(B, 16, generator=gen).cuda()
+        ref = None
+        for on in (0, 1, 1, 1, 1):
+            lib.shm_set_pair_launch(on)
+            try:
+                if train_mode:
+                    torch.manual_seed(11)
+                    m2 = TemporalVAE(4, 16, H, 2, 0.3, precision="bf16").cuda().train()
+                    tr = VAETrainer(m2, lr=1e-3, weight_decay=1e-5, max_norm=2.0)
+                    stats = tr.step(x, 0.3, eps=eps, drop_seed=99)
+                    out = (stats.clone(), tr.grads.clone())
+                    tr.engine.check_status()
+                else:
+                    m.eval()
+                    with torch.no_grad(), inject_eps([eps.cpu()]):
+                        out = m(x)
+                    m._engine.check_status()
+            finally:
+                lib.shm_set_pair_launch(1)
+            if ref is None:
+                ref = out
+            else:
+                for a, b in zip(ref, out):
+                    assert torch.equal(a, b), (B, T, H, on, float((a - b).abs().max()))
