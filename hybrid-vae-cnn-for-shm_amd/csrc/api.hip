@@ -60,6 +60,7 @@ struct shm_vae_plan {
     // workspace byte offsets
     size_t h_last, eps, y, xhat, rstd, mu, lv, z, h0, dpre_l2h, dmu, dlv, dyx, dy, dh_last, dh0;
     size_t recon, score, d_recon, d_mu, d_lv, dpre_seq, dx_seq, dpre_tsum, gemm_partial, colsum_scratch;
+    size_t dpre_seq2, dpre_tsum2;   // bf16 path, 2 layers: the top layer's dpre / sum_t dpre (both layers' live at once in a pair launch)
     size_t gemm_partial_elems;
     size_t narrow_scratch;  // block partials of narrow_tn
     size_t pair_sync;       // bf16 path, 2 layers: ticket / error / progress words of the layer-pipelined launches
@@ -250,6 +251,7 @@ extern "C" int shm_vae_plan_create(const shm_vae_config* cfg, int32_t B, int32_t
         p->recon = take(BT * D); p->d_recon = take(BT * D); p->d_mu = take((size_t)B * Z); p->d_lv = take((size_t)B * Z);
         p->dpre_seq = bf ? take_bytes(2 * Rq * 4 * H) : take(BT * 4 * H);   // bf16: whole tiles (unconditional stores)
         p->dx_seq = take(bf ? Rq * H : BT * H); p->dpre_tsum = take((size_t)B * 4 * H);
+        if (bf && L == 2) { p->dpre_seq2 = take_bytes(2 * Rq * 4 * H); p->dpre_tsum2 = take((size_t)B * 4 * H); }
         size_t gp = 0;
         auto upd = [&](int R, int M, int N) { const size_t e = gemm_tn_partial_elems(R, M, N); if (e > gp) gp = e; };
         upd((int)BT, H, D); upd((int)BT, 4 * H, H); upd((int)BT, 4 * H, D); upd(B, 4 * H, H); upd(B, H, Z); upd(B, Z, H);
@@ -505,26 +507,66 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
     }
 
     auto run_stack_bwd = [&](LayerInst* st, uint32_t stack, const float* x0, bool is_dec) -> int {
+        const int Rt = ceil_div(B, SHM_WPT) * SHM_WPT * T;   // bf16 rows incl. tile padding (padding rows of dpre are exactly zero)
+        auto bwd_args_bf = [&](int l, bf16_t* dps, float* tsum) {
+            LstmBwdArgsB a;
+            memset(&a, 0, sizeof(a));
+            a.sv_g = at<bf16_t>(ws, st[l].saved);
+            if (l == L - 1) {
+                if (is_dec) { a.dy = d_recon; a.Wout = prm + p->out_w; a.Dy = D; }
+                else a.dh_last = hb.dh_last;
+            } else {
+                a.dh_seq = dx_seq;
+            }
+            a.WhT = at<bf16_t>(ws, st[l].WhT);
+            a.need_dx = l > 0 ? 1 : 0;
+            a.WxT = l > 0 ? at<bf16_t>(ws, st[l].WxT) : nullptr;
+            a.dpre_seq = dps; a.dpre_tsum = tsum; a.dx_seq = dx_seq;
+            a.B = B; a.T = T; a.In = st[l].In;
+            a.drop_p = l > 0 ? drop : 0.f; a.drop_seed = p->drop_seed; a.drop_stack = stack;
+            return a;
+        };
+        // deferred weight / bias gradients of layer l from its stored dpre sequence
+        auto layer_grads_bf = [&](int l, const void* dps, const float* tsum) -> int {
+            int r;
+            if (l > 0) {      // with dropout the forward left the masked input in xdrop: no re-hashing in the GEMM
+                const void* xin = drop > 0.f ? at<char>(ws, st[l].xdrop) : at<char>(ws, st[l - 1].h_seq);
+                if ((r = gemm_bf(dps, G, xin, grads + st[l].w_ih, 0.f, stack, at<char>(ws, st[l].h_seq), grads + st[l].w_hh, Rt))) return r;
+            } else if ((r = gemm_bf(dps, G, nullptr, nullptr, 0.f, 0, at<char>(ws, st[l].h_seq), grads + st[l].w_hh, Rt))) return r;
+            if (l > 0) {
+            } else if (st[l].in_const) {
+                if ((r = gemm(tsum, G, G, hb.h0, H, H, B, grads + st[l].w_ih, 0, 0, 0.f, 0))) return r;
+            } else {
+                if ((r = launch_narrow_tn(dps, 1, G, G, x0, D, Rt, grads + st[l].w_ih, 1, nullptr, at<float>(ws, p->narrow_scratch), s, T, B))) return r;
+            }
+            return launch_colsum(tsum, G, B, G, grads + st[l].b_ih, grads + st[l].b_hh, cs, s);
+        };
+        if (bf && L == 2 && pair_launch_enabled()) {
+            // both layers in one launch (layer 0 forms dx itself, a few steps behind layer 1); layer 0 keeps the primary
+            // dpre / tsum buffers because the head reads decoder layer 0's sum_t dpre
+            bf16_t* dps1 = at<bf16_t>(ws, p->dpre_seq2); float* tsum1 = at<float>(ws, p->dpre_tsum2);
+            LstmBwdPairArgsB pa;
+            pa.l1 = bwd_args_bf(1, dps1, tsum1); pa.l0 = bwd_args_bf(0, at<bf16_t>(ws, p->dpre_seq), dpre_tsum);
+            pa.sync = at<unsigned>(ws, p->pair_sync); pa.err = at<unsigned>(ws, p->pair_sync + lstm_fwd_pair_sync_bytes(B)); pa.role_lds_off = 0;
+            int r;
+            {
+                KernelTimer kt(stack == 0 ? "lstm_bwd.enc" : "lstm_bwd.dec", s);
+                r = launch_lstm_bwd_pair_bf16(H, pa, s);
+            }
+            if (r) return r;
+            {
+                KernelTimer kt(stack == 0 ? "dw_gemm.enc1" : "dw_gemm.dec1", s);
+                if ((r = layer_grads_bf(1, dps1, tsum1))) return r;
+            }
+            KernelTimer kt(stack == 0 ? "dw_gemm.enc0" : "dw_gemm.dec0", s);
+            return layer_grads_bf(0, at<char>(ws, p->dpre_seq), dpre_tsum);
+        }
         for (int l = L - 1; l >= 0; --l) {
             char nm[32], gnm[32];
             snprintf(nm, sizeof(nm), "lstm_bwd.%s%d", stack == 0 ? "enc" : "dec", l);
             snprintf(gnm, sizeof(gnm), "dw_gemm.%s%d", stack == 0 ? "enc" : "dec", l);
             if (bf) {
-                LstmBwdArgsB a;
-                memset(&a, 0, sizeof(a));
-                a.sv_g = at<bf16_t>(ws, st[l].saved);
-                if (l == L - 1) {
-                    if (is_dec) { a.dy = d_recon; a.Wout = prm + p->out_w; a.Dy = D; }
-                    else a.dh_last = hb.dh_last;
-                } else {
-                    a.dh_seq = dx_seq;
-                }
-                a.WhT = at<bf16_t>(ws, st[l].WhT);
-                a.need_dx = l > 0 ? 1 : 0;
-                a.WxT = l > 0 ? at<bf16_t>(ws, st[l].WxT) : nullptr;
-                a.dpre_seq = at<bf16_t>(ws, p->dpre_seq); a.dpre_tsum = dpre_tsum; a.dx_seq = dx_seq;
-                a.B = B; a.T = T; a.In = st[l].In;
-                a.drop_p = l > 0 ? drop : 0.f; a.drop_seed = p->drop_seed; a.drop_stack = stack;
+                const LstmBwdArgsB a = bwd_args_bf(l, at<bf16_t>(ws, p->dpre_seq), dpre_tsum);
                 int r;
                 {
                     KernelTimer kt(nm, s);
@@ -538,19 +580,7 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
                     if ((r = launch_dx_gemm_bf16(H, a, s))) return r;
                 }
                 KernelTimer kt(gnm, s);
-                const void* dps = at<char>(ws, p->dpre_seq);
-                const int Rt = ceil_div(B, SHM_WPT) * SHM_WPT * T;   // rows incl. tile padding (padding rows of dpre are exactly zero)
-                if (l > 0) {      // with dropout the forward left the masked input in xdrop: no re-hashing in the GEMM
-                    const void* xin = drop > 0.f ? at<char>(ws, st[l].xdrop) : at<char>(ws, st[l - 1].h_seq);
-                    if ((r = gemm_bf(dps, G, xin, grads + st[l].w_ih, 0.f, stack, at<char>(ws, st[l].h_seq), grads + st[l].w_hh, Rt))) return r;
-                } else if ((r = gemm_bf(dps, G, nullptr, nullptr, 0.f, 0, at<char>(ws, st[l].h_seq), grads + st[l].w_hh, Rt))) return r;
-                if (l > 0) {
-                } else if (st[l].in_const) {
-                    if ((r = gemm(dpre_tsum, G, G, hb.h0, H, H, B, grads + st[l].w_ih, 0, 0, 0.f, 0))) return r;
-                } else {
-                    if ((r = launch_narrow_tn(dps, 1, G, G, x0, D, Rt, grads + st[l].w_ih, 1, nullptr, at<float>(ws, p->narrow_scratch), s, T, B))) return r;
-                }
-                if ((r = launch_colsum(dpre_tsum, G, B, G, grads + st[l].b_ih, grads + st[l].b_hh, cs, s))) return r;
+                if ((r = layer_grads_bf(l, at<char>(ws, p->dpre_seq), dpre_tsum))) return r;
                 continue;
             }
             LstmBwdArgs a;

@@ -141,6 +141,10 @@ struct LstmBwdArgsB {
 };
 int launch_lstm_bwd_bf16(int H, const LstmBwdArgsB& a, hipStream_t s);      // recurrent part: dpre_seq, dpre_tsum
 int launch_dx_gemm_bf16(int H, const LstmBwdArgsB& a, hipStream_t s);       // time-parallel part: dx_seq = dpre_seq . W_ih
+// both layers of a 2-layer stack in one launch: l1 = top layer (its dpre_seq is handed to l0 inside the launch), l0 forms
+// dx = dpre^1 W_ih^1 itself; the two dpre_seq / dpre_tsum buffers must be distinct
+struct LstmBwdPairArgsB { LstmBwdArgsB l1, l0; unsigned* sync; unsigned* err; int role_lds_off; };
+int launch_lstm_bwd_pair_bf16(int H, const LstmBwdPairArgsB& p, hipStream_t s);
 
 struct GemmTnArgsB {
     const void* A; int lda;        // [R, M] bf16 (dpre_seq)

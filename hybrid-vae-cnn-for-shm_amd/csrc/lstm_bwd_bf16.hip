@@ -18,6 +18,14 @@
 //   saved records   : one 16-byte record per cell and step, fragment order (written by the forward).
 // Quad tiles / one cell per lane: see lstm_fwd_bf16.hip.  After the third ablation (per-CU HBM load bandwidth, ~25 GB/s, was
 // the limiter with 16-window tiles on 32 CUs) a workgroup owns 4 windows: 128 CUs, 20 B of loads per lane and step.
+//
+// Layer pipelining (lstm_bwd_pair_bf16_kernel, 2-layer stacks): ONE launch of 2 x tiles workgroups.  The top layer's
+// workgroup of tile i writes dpre^1_t write-through (sc1) and publishes its progress DLY steps late (counted vmcnt, see
+// lstm_fwd_bf16.hip); the layer-0 workgroup of tile i follows a few steps behind and forms the gradient on its own h_t
+//     dx_t = dpre^1_t W_ih^1   (inter-layer dropout mask re-applied)
+// itself, four steps at a time (16 MFMA rows = 4 steps x 4 windows, W_ih^1T fragments in registers) from sc1 loads of the
+// top layer's dpre rows: the dx sequence is never written to HBM, and the two recurrences overlap on 2 x 128 CUs.  Roles
+// come from a ticket, so a consumer only ever waits for a workgroup that is already running.
 #include "kernels.hpp"
 
 namespace shm {
@@ -25,6 +33,15 @@ namespace shm {
 namespace {
 
 constexpr int WPT = SHM_WPT;     // windows per workgroup (see lstm_fwd_bf16.hip: quad tiles, one cell per lane)
+constexpr int DLY = 4;           // pair launch: a step's dpre rows are published DLY steps after they were stored
+constexpr unsigned SPIN_MAX = 1u << 21;
+
+typedef __attribute__((address_space(1))) unsigned gu32;
+#define SHM_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+template <int V> struct IntC { static constexpr int value = V; };
 
 struct Prefetch {            // operands of one time step of this lane's cell, fetched PD = 3 steps ahead
     u32x4 rec;               // {i,f | g,o (bf16x2 each), c_{t-1}, tanh(c_t)} written by the forward
@@ -37,8 +54,9 @@ struct Prefetch {            // operands of one time step of this lane's cell, f
 // 3: output layer with any other channel count (dy.W_out evaluated inside the fetch: synchronous fallback).
 // The time loop is branch-free: loads are clamped, never predicated, and T % 3 steps are peeled, so that the compiler can
 // count the loads in flight across the back-edge instead of draining them (s_waitcnt vmcnt(0)) at every loop header.
-template <int H, int DH>
-__global__ void __launch_bounds__(4 * H) lstm_bwd_bf16_kernel(LstmBwdArgsB a) {
+// PRODUCE: dpre_seq is consumed by the layer-0 workgroup of the same tile inside this launch (flag_out).
+template <int H, int DH, bool PRODUCE>
+__device__ __forceinline__ void lstm_bwd_body(const LstmBwdArgsB& a, const int tile, gu32* flag_out) {
     constexpr int NW = H / 16, NTHR = 64 * NW;
     constexpr int KS = H / 8;                      // k-steps of 32 over K = 4H
     constexpr int RS = lds_row_stride(H);          // quarter q <-> gate q, KQ = H
@@ -50,12 +68,15 @@ __global__ void __launch_bounds__(4 * H) lstm_bwd_bf16_kernel(LstmBwdArgsB a) {
 
     const int T = a.T, B = a.B, Dy = a.Dy;
     const int tid = threadIdx.x, lane = tid & 63, ht = tid >> 6, q = lane >> 4, j = lane & 15;
-    const int tile = blockIdx.x;
     const int cj = j & 3, cr = j >> 2, cu = ht * 16 + q * 4 + cr;          // my cell: window cj of the tile, unit cu
     const int cb = tile * WPT + cj;
     const bool cvalid = cb < B;
     const int bc = cvalid ? cb : B - 1;            // clamped window for loads; its contribution is zeroed through vmask
     const float vmask = cvalid ? 1.f : 0.f;
+    // vector-memory instructions a dpre-storing wave issues per step (record, upstream gradient, dpre), a lower bound
+    constexpr int OPS = 2 + ((DH == 1 || DH == 2) ? 1 : 0);
+    const __amdgpu_buffer_rsrc_t out_rsrc = make_rsrc(PRODUCE ? a.dpre_seq + (size_t)tile * T * WPT * 4 * H : nullptr,
+                                                      PRODUCE ? (uint32_t)T * WPT * 4 * H * 2 : 0);
 
     for (int e = tid; e < 2 * PBUF; e += NTHR) smem_b[e] = (bf16_t)0.f;   // image rows j >= WPT stay zero
     if (DH >= 2)
@@ -128,13 +149,23 @@ __global__ void __launch_bounds__(4 * H) lstm_bwd_bf16_kernel(LstmBwdArgsB a) {
         }
         fetch(P, t - 3);                                   // refill the slot: 3 steps of latency cover
         __syncthreads();
+        // every storing wave has, in step t+1, waited until its dpre store of step t+DLY had retired
+        if constexpr (PRODUCE) {
+            if (tid == 0 && t + DLY <= T - 1) __hip_atomic_store(flag_out, (unsigned)(T - (t + DLY)), SHM_RLX_AGENT);
+        }
         // dpre_t -> HBM out of the now complete image: the WPT x 4H block of (tile, t) is contiguous in dpre_seq
         {
             constexpr int NCH = WPT * 4 * H / 8;           // 16-byte chunks (<= NTHR)
             if (tid < NCH) {
                 const int jj = tid / (4 * H / 8), c8 = (tid - jj * (4 * H / 8)) * 8, g = c8 / H, u = c8 - g * H;
-                *reinterpret_cast<bf16x8*>(a.dpre_seq + ((size_t)tile * T + t) * WPT * 4 * H + (size_t)tid * 8) =
-                    *reinterpret_cast<const bf16x8*>(dpl + (g * 16 + jj) * RS + u);
+                if constexpr (PRODUCE) {
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(dpl + (g * 16 + jj) * RS + u);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, (uint32_t)(t * WPT * 4 * H + tid * 8) * 2, 0, 16);
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DLY - 1) * OPS) : "memory");   // retires the store of step t+DLY-1
+                } else {
+                    *reinterpret_cast<bf16x8*>(a.dpre_seq + ((size_t)tile * T + t) * WPT * 4 * H + (size_t)tid * 8) =
+                        *reinterpret_cast<const bf16x8*>(dpl + (g * 16 + jj) * RS + u);
+                }
             }
         }
         const bf16_t* brow = dpl + (q * 16 + j) * RS;
@@ -167,10 +198,209 @@ __global__ void __launch_bounds__(4 * H) lstm_bwd_bf16_kernel(LstmBwdArgsB a) {
         step(P1, t - 1);
         step(P2, t - 2);
     }
+    if constexpr (PRODUCE) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(flag_out, (unsigned)T, SHM_RLX_AGENT);
+    }
     if (cvalid && a.dpre_tsum) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) a.dpre_tsum[(size_t)cb * 4 * H + g * H + cu] = tsum[g];
     }
+}
+
+template <int H, int DH>
+__global__ void __launch_bounds__(4 * H) lstm_bwd_bf16_kernel(LstmBwdArgsB a) {
+    lstm_bwd_body<H, DH, false>(a, blockIdx.x, nullptr);
+}
+
+// Layer 0 of a pair launch: BPTT of the layer below `up`, with dx_t = dpre^up_t W_ih^up formed here (see the file header).
+// Chunk c = steps 4c..4c+3 of the tile = 16 consecutive rows of up.dpre_seq.  While the recurrence walks chunk c (t descending),
+// the rows of chunk c-1 go from registers into the LDS image (sub-step 3) and through the MFMA into dxbuf (sub-step 2), and
+// the rows of chunk c-2 are requested: every global access is 4 steps or more ahead of its use.
+template <int H, bool DROP>
+__device__ __forceinline__ void lstm_bwd_fused_dx_body(const LstmBwdArgsB& a, const LstmBwdArgsB& up, const int tile, gu32* flag_in, gu32* err) {
+    static_assert(WPT == 4, "a 16-row MFMA tile = 4 steps x 4 windows");
+    constexpr int NW = H / 16, NTHR = 64 * NW, KS = H / 8, RS = lds_row_stride(H), PBUF = 4 * 16 * RS;
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem_b[];
+    bf16_t* dp_lds = smem_b;                                               // [2][PBUF] this layer's dpre_t
+    bf16_t* dx_img = smem_b + 2 * PBUF;                                    // [PBUF] 16 rows of the upper layer's dpre
+    float* scr = reinterpret_cast<float*>(smem_b + 3 * PBUF);              // [NW][64] accumulator re-deal scratch
+    float* dxbuf = scr + NW * 64;                                          // [2][16 rows][H] dx of two chunks
+
+    const int T = a.T, B = a.B;
+    const int tid = threadIdx.x, lane = tid & 63, ht = tid >> 6, q = lane >> 4, j = lane & 15;
+    const int cj = j & 3, cr = j >> 2, cu = ht * 16 + q * 4 + cr;
+    const int cb = tile * WPT + cj;
+    const bool cvalid = cb < B;
+    const float vmask = cvalid ? 1.f : 0.f;
+
+    for (int e = tid; e < 2 * PBUF; e += NTHR) smem_b[e] = (bf16_t)0.f;   // image rows j >= WPT stay zero
+
+    bf16x8 whT[KS], wxT[KS];
+    {
+        const bf16x8* p = reinterpret_cast<const bf16x8*>(a.WhT) + (size_t)ht * KS * 64 + lane;
+        const bf16x8* px = reinterpret_cast<const bf16x8*>(up.WxT) + (size_t)ht * KS * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) { whT[s] = p[s * 64]; wxT[s] = px[s * 64]; }
+    }
+    const uint32_t thr = drop_threshold(up.drop_p);
+    const float dscale = DROP ? 1.0f / (1.0f - up.drop_p) : 1.0f;
+
+    const u32x4* sv = reinterpret_cast<const u32x4*>(a.sv_g) + ((size_t)tile * T * NW + ht) * 64 + lane;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto fetch = [&](u32x4& R, int t) { R = sv[(size_t)(t < 0 ? 0 : t) * NW * 64]; };
+
+    // ---- the upper layer's dpre rows: sc1 loads behind the producer's progress word
+    const __amdgpu_buffer_rsrc_t up_rsrc = make_rsrc(up.dpre_seq + (size_t)tile * T * WPT * 4 * H, (uint32_t)T * WPT * 4 * H * 2);
+    int avail = 0;                                         // wave-uniform: the producer's steps >= T - avail are in memory
+    auto wait_for = [&](int need) {
+        if (avail >= need) return;
+        unsigned v, spins = 0;
+#pragma clang loop unroll(disable)
+        for (;;) {
+            v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flag_in, SHM_RLX_AGENT));
+            if ((int)v >= need) break;
+            if (++spins > SPIN_MAX) {                      // give up: finish with garbage, flagged in the err word
+                if (lane == 0) __hip_atomic_store(err, 0x80000001u + (unsigned)tile, SHM_RLX_AGENT);
+                v = 0x7fffffff;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        avail = (int)v;
+    };
+    constexpr int CPT = (16 * 4 * H / 8) / NTHR;           // = 2 16-byte pieces per thread and chunk
+    bf16x8 ck[CPT];
+    auto chunk_load = [&](int c) {                         // rows of steps >= T read as zero (buffer range check)
+        const int cc = c < 0 ? 0 : c;
+        wait_for(T - 4 * cc);
+#pragma unroll
+        for (int i = 0; i < CPT; ++i)
+            ck[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(up_rsrc, (uint32_t)(cc * 16 * 4 * H + (tid + i * NTHR) * 8) * 2, 0, 16));
+    };
+    auto chunk_commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int e = tid + i * NTHR, jj = e / (4 * H / 8), c8 = (e - jj * (4 * H / 8)) * 8, g = c8 / H, u = c8 - g * H;
+            asm volatile("" : "+v"(ck[i]));
+            *reinterpret_cast<bf16x8*>(dx_img + (g * 16 + jj) * RS + u) = ck[i];
+        }
+    };
+    auto chunk_mma = [&](int c) {                          // same contraction order and mask indexing as dx_gemm_bf16_kernel
+        const bf16_t* brow = dx_img + (q * 16 + j) * RS;
+        f32x4 acc0 = zero4, acc1 = zero4;
+#pragma unroll
+        for (int s = 0; s < KS; s += 2) {
+            const bf16x8 bv0 = *reinterpret_cast<const bf16x8*>(brow + 8 * s);
+            const bf16x8 bv1 = *reinterpret_cast<const bf16x8*>(brow + 8 * s + 8);
+            acc0 = mfma_bf16_16x16x32(wxT[s], bv0, acc0);
+            acc1 = mfma_bf16_16x16x32(wxT[s + 1], bv1, acc1);
+        }
+        f32x4 d = acc0 + acc1;
+        if (DROP) {
+            const uint32_t base = (uint32_t)((((size_t)tile * T + 4 * c) * WPT + j) * H + ht * 16 + q * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = drop_hash(up.drop_seed, up.drop_stack, base + e) >= thr ? d[e] * dscale : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(dxbuf + (((c & 1) * 16) + j) * H + ht * 16 + q * 4) = d;
+    };
+
+    float dc = 0.f, dh_rec = 0.f;
+    float tsum[4] = {0.f, 0.f, 0.f, 0.f};
+    float* myscr = scr + ht * 64;
+
+    auto step = [&](u32x4& R, int t, auto subc) {
+        constexpr int SUB = decltype(subc)::value;         // t & 3 in the main loop, -1 in the peeled steps
+        asm volatile("" : "+v"(R));
+        bf16_t* dpl = dp_lds + (t & 1) * PBUF;
+        const int c = t >> 2;
+        const float dha = dxbuf[(((c & 1) * 16) + (t & 3) * 4 + cj) * H + cu];
+        const float s_i = __uint_as_float(R[0] << 16), s_f = __uint_as_float(R[0] & 0xffff0000u);
+        const float s_g = __uint_as_float(R[1] << 16), s_o = __uint_as_float(R[1] & 0xffff0000u);
+        const float c_prev = __uint_as_float(R[2]), tc = __uint_as_float(R[3]);
+        float dpre[4];
+        {
+            const float dh = dha * vmask + dh_rec;
+            const float d_o = dh * tc;
+            const float dcr = dc + dh * s_o * (1.0f - tc * tc);
+            const float d_i = dcr * s_g, d_g = dcr * s_i, d_f = dcr * c_prev;
+            dc = dcr * s_f;
+            dpre[0] = d_i * s_i * (1.0f - s_i);
+            dpre[1] = d_f * s_f * (1.0f - s_f);
+            dpre[2] = d_g * (1.0f - s_g * s_g);
+            dpre[3] = d_o * s_o * (1.0f - s_o);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            dpl[(g * 16 + cj) * RS + cu] = (bf16_t)dpre[g];
+            tsum[g] += dpre[g];
+        }
+        fetch(R, t - 4);
+        if constexpr (SUB == 3) { chunk_commit(); chunk_load(c - 2); }
+        __syncthreads();
+        {
+            constexpr int NCH = WPT * 4 * H / 8;
+            if (tid < NCH) {
+                const int jj = tid / (4 * H / 8), c8 = (tid - jj * (4 * H / 8)) * 8, g = c8 / H, u = c8 - g * H;
+                *reinterpret_cast<bf16x8*>(a.dpre_seq + ((size_t)tile * T + t) * WPT * 4 * H + (size_t)tid * 8) =
+                    *reinterpret_cast<const bf16x8*>(dpl + (g * 16 + jj) * RS + u);
+            }
+        }
+        const bf16_t* brow = dpl + (q * 16 + j) * RS;
+        f32x4 acc0 = zero4, acc1 = zero4;
+#pragma unroll
+        for (int s = 0; s < KS; s += 2) {
+            const bf16x8 bv0 = *reinterpret_cast<const bf16x8*>(brow + 8 * s);
+            const bf16x8 bv1 = *reinterpret_cast<const bf16x8*>(brow + 8 * s + 8);
+            acc0 = mfma_bf16_16x16x32(whT[s], bv0, acc0);
+            acc1 = mfma_bf16_16x16x32(whT[s + 1], bv1, acc1);
+        }
+        if constexpr (SUB == 2) chunk_mma(c - 1);
+        if (j < WPT) *reinterpret_cast<f32x4*>(myscr + (q * 4 + j) * 4) = acc0 + acc1;
+        __builtin_amdgcn_wave_barrier();
+        dh_rec = myscr[(q * 4 + cj) * 4 + cr];
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    __syncthreads();                                       // images zeroed
+    auto sync_chunk = [&](int c) { chunk_load(c); chunk_commit(); __syncthreads(); chunk_mma(c); __syncthreads(); };
+    const int ctop = (T - 1) >> 2;
+    int c1 = ctop;
+    sync_chunk(ctop);
+    if (T & 3) { c1 = ctop - 1; if (c1 >= 0) sync_chunk(c1); }      // the peeled steps use the partial top chunk
+    chunk_load(c1 - 1);
+
+    u32x4 R0, R1, R2, R3;
+    int t = T - 1;
+    for (int k = T & 3; k > 0; --k, --t) { fetch(R0, t); step(R0, t, IntC<-1>{}); }
+    fetch(R0, t); fetch(R1, t - 1); fetch(R2, t - 2); fetch(R3, t - 3);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0) once (see lstm_bwd_body)
+    for (; t >= 3; t -= 4) {
+        step(R0, t, IntC<3>{});
+        step(R1, t - 1, IntC<2>{});
+        step(R2, t - 2, IntC<1>{});
+        step(R3, t - 3, IntC<0>{});
+    }
+    if (cvalid && a.dpre_tsum) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) a.dpre_tsum[(size_t)cb * 4 * H + g * H + cu] = tsum[g];
+    }
+}
+
+// sync: [0] ticket, flag of tile i at sync[16 * (1 + i)], zeroed by the launcher; err: sticky word outside that block
+template <int H, int DHTOP, bool DROP>
+__global__ void __launch_bounds__(4 * H) lstm_bwd_pair_bf16_kernel(LstmBwdPairArgsB p) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem_b[];
+    gu32* sync = (gu32*)p.sync;
+    const int tiles = gridDim.x >> 1;
+    int* role_lds = reinterpret_cast<int*>(reinterpret_cast<char*>(smem_b) + p.role_lds_off);
+    if (threadIdx.x == 0) *role_lds = (int)__hip_atomic_fetch_add(sync, 1u, SHM_RLX_AGENT);
+    __syncthreads();
+    const int role = *role_lds;
+    __syncthreads();
+    if (role < tiles) lstm_bwd_body<H, DHTOP, true>(p.l1, role, sync + 16 * (1 + role));
+    else lstm_bwd_fused_dx_body<H, DROP>(p.l0, p.l1, role - tiles, sync + 16 * (1 + role - tiles), (gu32*)p.err);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -267,7 +497,43 @@ int launch_dx(const LstmBwdArgsB& a, hipStream_t s) {
     return SHM_OK;
 }
 
+template <int H>
+int launch_pair(const LstmBwdPairArgsB& p0, hipStream_t s) {
+    LstmBwdPairArgsB p = p0;
+    const LstmBwdArgsB &t = p.l1, &b = p.l0;
+    SHM_REQUIRE(t.sv_g && b.sv_g && t.dpre_seq && b.dpre_seq && t.dpre_seq != b.dpre_seq, SHM_ESTATE, "lstm_bwd_pair: saved state / two dpre buffers needed");
+    SHM_REQUIRE(t.WhT && b.WhT && t.WxT && t.In == H, SHM_EINVAL, "lstm_bwd_pair: packed weights missing");
+    SHM_REQUIRE(t.B == b.B && t.T == b.T && p.sync && p.err, SHM_EINVAL, "lstm_bwd_pair: shape mismatch or no sync block");
+    SHM_REQUIRE(!t.dy || (t.Wout && t.Dy > 0 && t.Dy <= 64), SHM_EINVAL, "lstm_bwd_pair: bad output-layer gradient");
+    SHM_REQUIRE((int64_t)t.T * WPT * 4 * H * 2 < ((int64_t)1 << 31), SHM_EINVAL, "lstm_bwd_pair: T too long for 32-bit buffer offsets");
+    const int tiles = ceil_div(t.B, WPT);
+    const size_t img = sizeof(bf16_t) * 4 * 16 * lds_row_stride(H);
+    const size_t lds_top = 2 * img + sizeof(float) * ((H / 16) * 64 + (t.dy ? t.Dy * H : 0));
+    const size_t lds_bot = 3 * img + sizeof(float) * ((H / 16) * 64 + 2 * 16 * H);
+    const size_t lds = ((lds_top > lds_bot ? lds_top : lds_bot) + 15) & ~(size_t)15;
+    p.role_lds_off = (int)lds;
+    SHM_HIP_CHECK(hipMemsetAsync(p.sync, 0, lstm_fwd_pair_sync_bytes(t.B), s));
+    const bool drop = t.drop_p > 0.f;
+    void (*kern)(LstmBwdPairArgsB);
+    if (t.dy) kern = t.Dy == 4 ? (drop ? lstm_bwd_pair_bf16_kernel<H, 2, true> : lstm_bwd_pair_bf16_kernel<H, 2, false>)
+                               : (drop ? lstm_bwd_pair_bf16_kernel<H, 3, true> : lstm_bwd_pair_bf16_kernel<H, 3, false>);
+    else kern = drop ? lstm_bwd_pair_bf16_kernel<H, 0, true> : lstm_bwd_pair_bf16_kernel<H, 0, false>;
+    hipLaunchKernelGGL(kern, dim3(2 * tiles), dim3(4 * H), lds + 16, s, p);
+    SHM_LAUNCH_CHECK();
+    return SHM_OK;
+}
+
 }  // namespace
+
+int launch_lstm_bwd_pair_bf16(int H, const LstmBwdPairArgsB& p, hipStream_t s) {
+    SHM_REQUIRE(p.l1.B > 0 && p.l1.T > 0, SHM_EINVAL, "lstm_bwd_pair: empty shape");
+    switch (H) {
+        case 32: return launch_pair<32>(p, s);
+        case 64: return launch_pair<64>(p, s);
+        case 128: return launch_pair<128>(p, s);
+        default: set_error("lstm_bwd_pair: hidden_dim %d unsupported (32, 64, 128)", H); return SHM_EINVAL;
+    }
+}
 
 int launch_lstm_bwd_bf16(int H, const LstmBwdArgsB& a, hipStream_t s) {
     SHM_REQUIRE(a.B > 0 && a.T > 0, SHM_EINVAL, "lstm_bwd_bf16: empty shape");
