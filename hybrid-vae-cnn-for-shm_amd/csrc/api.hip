@@ -63,7 +63,8 @@ struct shm_vae_plan {
     size_t dpre_seq2, dpre_tsum2;   // bf16 path, 2 layers: the top layer's dpre / sum_t dpre (both layers' live at once in a pair launch)
     size_t gemm_partial_elems;
     size_t narrow_scratch;  // block partials of narrow_tn
-    size_t pair_sync;       // bf16 path, 2 layers: ticket / error / progress words of the layer-pipelined launches
+    size_t pair_sync;       // bf16 path, 2 layers: ticket / progress words of the layer-pipelined launches (zeroed per launch)
+    size_t misc;            // bf16 path: [64 B sticky error word of the pair launches][256 zero bytes], zeroed by pack_weights
     size_t params_copy;     // flat fp32 copy of the parameters (head / output layer read them unpacked)
     size_t ws_bytes;
     // call-order state
@@ -239,7 +240,8 @@ extern "C" int shm_vae_plan_create(const shm_vae_config* cfg, int32_t B, int32_t
             }
         }
     }
-    if (bf && L == 2) p->pair_sync = take_bytes(lstm_fwd_pair_sync_bytes(B) + 64);   // + the sticky error word
+    if (bf && L == 2) p->pair_sync = take_bytes(lstm_fwd_pair_sync_bytes(B));
+    if (bf) p->misc = take_bytes(64 + 256);
     p->params_copy = take((size_t)p->n_params);
     p->h_last = take((size_t)B * H); p->eps = take((size_t)B * Z);
     p->y = take((size_t)B * H); p->xhat = take((size_t)B * H); p->rstd = take(B);
@@ -290,7 +292,7 @@ extern "C" int shm_vae_pack_weights(shm_vae_plan* p, const float* params, void* 
     hipStream_t s = (hipStream_t)stream;
     const int H = p->cfg.hidden_dim, L = p->cfg.num_layers;
     SHM_HIP_CHECK(hipMemcpyAsync(at<float>(ws, p->params_copy), params, sizeof(float) * p->n_params, hipMemcpyDeviceToDevice, s));
-    if (p->pair_sync) SHM_HIP_CHECK(hipMemsetAsync(at<char>(ws, p->pair_sync + lstm_fwd_pair_sync_bytes(p->B)), 0, 64, s));
+    if (p->cfg.precision == SHM_PREC_BF16) SHM_HIP_CHECK(hipMemsetAsync(at<char>(ws, p->misc), 0, 64 + 256, s));
     if (p->cfg.precision == SHM_PREC_BF16) {          // bf16 path: every re-layout in one launch
         PackJobs jobs;
         jobs.n = 0;
@@ -372,7 +374,7 @@ extern "C" int shm_vae_forward(shm_vae_plan* p, const float* x, const float* eps
         if (c.precision == SHM_PREC_BF16 && L == 2 && pair_launch_enabled()) {   // both layers in one launch, layer 1 a few steps behind
             LstmFwdPairArgsB pa;
             pa.l0 = fwd_args(0); pa.l1 = fwd_args(1); pa.sync = at<unsigned>(ws, p->pair_sync); pa.role_lds_off = 0;
-            pa.err = at<unsigned>(ws, p->pair_sync + lstm_fwd_pair_sync_bytes(B));
+            pa.err = at<unsigned>(ws, p->misc);
             KernelTimer kt(stack == 0 ? "lstm_fwd.enc" : "lstm_fwd.dec", s);
             return launch_lstm_fwd_pair_bf16(H, pa, s);
         }
@@ -432,7 +434,7 @@ extern "C" int shm_vae_plan_status(const shm_vae_plan* p, const void* ws, void* 
     if (rc) return rc;
     if (!p->pair_sync) return SHM_OK;
     unsigned word = 0;
-    SHM_HIP_CHECK(hipMemcpyAsync(&word, reinterpret_cast<const char*>(ws) + p->pair_sync + lstm_fwd_pair_sync_bytes(p->B), 4,
+    SHM_HIP_CHECK(hipMemcpyAsync(&word, reinterpret_cast<const char*>(ws) + p->misc, 4,
                                  hipMemcpyDeviceToHost, (hipStream_t)stream));
     SHM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     SHM_REQUIRE(word == 0, SHM_ESTATE, "layer-pipelined launch: the consumer of tile %u gave up waiting for its producer; results since the last "
@@ -485,6 +487,7 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
         else { g.NB = 1; g.Bm = Bh; g.C = Chh; g.shift_T = T; }
         g.drop_p = dp; g.drop_seed = p->drop_seed; g.drop_stack = stack;
         g.partial = at<float>(ws, p->gemm_partial); g.partial_elems = p->gemm_partial_elems;
+        g.zeros = at<char>(ws, p->misc + 64);
         return launch_gemm_tn_bf16(g, s);
     };
     auto gemm = [&](const void* A, int lda, int M, const void* Bm, int ldb, int N, int R, float* C, int shift_T, int trans_out,
@@ -547,7 +550,7 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
             bf16_t* dps1 = at<bf16_t>(ws, p->dpre_seq2); float* tsum1 = at<float>(ws, p->dpre_tsum2);
             LstmBwdPairArgsB pa;
             pa.l1 = bwd_args_bf(1, dps1, tsum1); pa.l0 = bwd_args_bf(0, at<bf16_t>(ws, p->dpre_seq), dpre_tsum);
-            pa.sync = at<unsigned>(ws, p->pair_sync); pa.err = at<unsigned>(ws, p->pair_sync + lstm_fwd_pair_sync_bytes(B)); pa.role_lds_off = 0;
+            pa.sync = at<unsigned>(ws, p->pair_sync); pa.err = at<unsigned>(ws, p->misc); pa.role_lds_off = 0;
             int r;
             {
                 KernelTimer kt(stack == 0 ? "lstm_bwd.enc" : "lstm_bwd.dec", s);

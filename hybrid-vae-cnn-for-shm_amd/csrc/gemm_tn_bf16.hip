@@ -137,7 +137,172 @@ __global__ void __launch_bounds__(256) gemm_tn_bf16_kernel(GemmTnArgsB a, int ti
             }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// v2 — the H = 128 shape (M % 256 == 0, N == 128): the kernel is bound by how many UNIQUE HBM bytes a CU keeps in flight
+// (v1 reached 2.2 TB/s: one 32 KB stage per workgroup in flight, 63 % of it re-reads of tiles other workgroups also load).
+//   * tile = 256 (M) x all N columns of BOTH products: A is read once per launch, B twice;
+//   * operands go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, no staging registers) into a ring of 4 stage buffers of
+//     32 rows, three stages (3 x 32 KB at NB = 2) in flight per CU, retired with counted s_waitcnt vmcnt and ONE raw
+//     s_barrier per stage (the wait precedes the barrier, the reads follow it; a buffer is refilled one barrier after its
+//     last read);
+//   * LDS-DMA writes lane-linear (1 KB per wave instruction, no padding possible), so the image is XOR-swizzled on the
+//     SOURCE side: the 32-byte block b of row r lands in block b ^ f(r), f(r) = 4*((r>>3)&1) + (r&3), which makes the 8 rows
+//     a half-wave touches in one ds_read_b64_tr_b16 hit 8 different bank groups;
+//   * rows past the split end and the t = 0 rows of the shifted product read a zero line instead of being branched around.
+constexpr int V2_KC = 32, V2_NBUF = 4, V2_MT = 256;
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_cvoid;
+__device__ __forceinline__ int v2_swz(int r) { return (((r >> 3) & 1) << 2) | (r & 3); }
+
+template <int NB>
+__global__ void __launch_bounds__(512) gemm_tn_bf16_v2_kernel(GemmTnArgsB a, int tiles_m, int rows_per_split, int nsplit) {
+    constexpr int NT = 128 * NB;                         // B image row: [product 0 | product 1]
+    constexpr int A_BYTES = V2_KC * V2_MT * 2, B_BYTES = V2_KC * NT * 2, ST_BYTES = A_BYTES + B_BYTES;
+    constexpr int GL_A = 2, GL_B = NB;                   // LDS-DMA instructions per wave and stage
+    constexpr int NJ = 2 * NB;                           // 16-column MFMA tiles per wave along N (wave tile 128 x 32*NB)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3, i16 = lane & 15;
+    const int wm = w >> 2, wn = w & 3;
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int tm = local % tiles_m, split = (local / tiles_m) * 8 + xcd;
+    if (split >= nsplit) return;
+    const int m0 = tm * V2_MT;
+    const int r_begin = split * rows_per_split, r_end = min(a.R, r_begin + rows_per_split);
+    const int nst = (r_end - r_begin + V2_KC - 1) / V2_KC;
+    const bf16_t* A = reinterpret_cast<const bf16_t*>(a.A);
+    const bf16_t* zeros = reinterpret_cast<const bf16_t*>(a.zeros);
+
+    // ---- per-lane LDS-DMA sources.  A: instruction j = 2w + i covers stage rows 2j, 2j+1 (512 B each): lane -> row l>>5, chunk l&31
+    int a_row[GL_A], a_col[GL_A];
+#pragma unroll
+    for (int i = 0; i < GL_A; ++i) {
+        const int rs = 2 * (2 * w + i) + (lane >> 5), c = lane & 31;
+        a_row[i] = rs; a_col[i] = (((c >> 1) ^ v2_swz(rs)) << 1 | (c & 1)) * 8;
+    }
+    // B: NB == 2: instruction j = 2w + i covers rows 2j, 2j+1 of [Bm | Bm2] (512 B); NB == 1: instruction w covers rows 4w..4w+3 (256 B)
+    int b_row[GL_B], b_col[GL_B], b_prod[GL_B];
+#pragma unroll
+    for (int i = 0; i < GL_B; ++i) {
+        int rs, c;
+        if (NB == 2) { rs = 2 * (2 * w + i) + (lane >> 5); c = lane & 31; }
+        else { rs = 4 * w + (lane >> 4); c = lane & 15; }
+        const int cs = ((c >> 1) ^ v2_swz(rs)) << 1 | (c & 1);       // source chunk of the [Bm | Bm2] row
+        b_row[i] = rs; b_prod[i] = cs >> 4; b_col[i] = (cs & 15) * 8;
+    }
+    auto issue = [&](int k) {                            // stage k -> ring slot k % NBUF (always issued: the counts stay static)
+        char* buf = smem + (k & (V2_NBUF - 1)) * ST_BYTES;
+        const int r0 = r_begin + k * V2_KC;
+#pragma unroll
+        for (int i = 0; i < GL_A; ++i) {
+            const int r = r0 + a_row[i];
+            const bf16_t* src = r < r_end ? A + (size_t)r * a.lda + m0 + a_col[i] : zeros;
+            __builtin_amdgcn_global_load_lds((gbl_cvoid*)src, (lds_void*)(buf + (2 * w + i) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < GL_B; ++i) {
+            const int r = r0 + b_row[i];
+            const bool second = NB == 2 ? b_prod[i] == 1 : false;
+            const bf16_t* base = reinterpret_cast<const bf16_t*>(second ? a.Bm2 : a.Bm);
+            const int sh = second ? a.shift_T2 : a.shift_T;
+            bool ok = r < r_end;
+            int rr = ok ? r : r_begin;
+            if (sh > 0) { ok = ok && ((rr / a.shift_rows) % sh != 0); rr -= a.shift_rows; }    // h_{t-1}, zero at t = 0
+            const bf16_t* src = ok ? base + (size_t)rr * a.ldb + b_col[i] : zeros;
+            __builtin_amdgcn_global_load_lds((gbl_cvoid*)src, (lds_void*)(buf + A_BYTES + ((NB == 2 ? 2 * w : 0) + (NB == 2 ? i : w)) * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[8][NJ];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int jn = 0; jn < NJ; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // transpose reads: lane (g, qq, pp) supplies row 8g + qq (+4), columns 4pp..4pp+3 of a 16-column block.
+    // The reads are inline asm: for a compiler-visible ds_read hipcc waits vmcnt(0) while any LDS-DMA is in flight (it cannot
+    // tell the ring slots apart), which would serialise the ring; ordering is ours — the counted vmcnt + barrier above.
+    const int tr_r = 8 * g + qq, fz = v2_swz(tr_r);      // v2_swz(tr_r + 4) == v2_swz(tr_r)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
+    uint32_t a_off[8], b_off[NJ];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a_off[i] = tr_r * (V2_MT * 2) + (((wm * 8 + i) ^ fz) << 5) + pp * 8;
+#pragma unroll
+    for (int jn = 0; jn < NJ; ++jn) b_off[jn] = A_BYTES + tr_r * (NT * 2) + (((wn * NJ + jn) ^ fz) << 5) + pp * 8;
+    auto compute = [&](int k) {
+        const uint32_t buf = lds0 + (k & (V2_NBUF - 1)) * ST_BYTES;
+        s16x4 alo[8], ahi[8], blo[NJ], bhi[NJ];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3"
+                         : "=&v"(alo[i]), "=&v"(ahi[i]) : "v"(buf + a_off[i]), "n"(4 * V2_MT * 2));
+#pragma unroll
+        for (int jn = 0; jn < NJ; ++jn)
+            asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3"
+                         : "=&v"(blo[jn]), "=&v"(bhi[jn]) : "v"(buf + b_off[jn]), "n"(4 * NT * 2));
+        if constexpr (NB == 2)
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(alo[0]), "+v"(ahi[0]), "+v"(alo[1]), "+v"(ahi[1]), "+v"(alo[2]), "+v"(ahi[2]), "+v"(alo[3]), "+v"(ahi[3]),
+                           "+v"(alo[4]), "+v"(ahi[4]), "+v"(alo[5]), "+v"(ahi[5]), "+v"(alo[6]), "+v"(ahi[6]), "+v"(alo[7]), "+v"(ahi[7]),
+                           "+v"(blo[0]), "+v"(bhi[0]), "+v"(blo[1]), "+v"(bhi[1]), "+v"(blo[2]), "+v"(bhi[2]), "+v"(blo[3]), "+v"(bhi[3]));
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(alo[0]), "+v"(ahi[0]), "+v"(alo[1]), "+v"(ahi[1]), "+v"(alo[2]), "+v"(ahi[2]), "+v"(alo[3]), "+v"(ahi[3]),
+                           "+v"(alo[4]), "+v"(ahi[4]), "+v"(alo[5]), "+v"(ahi[5]), "+v"(alo[6]), "+v"(ahi[6]), "+v"(alo[7]), "+v"(ahi[7]),
+                           "+v"(blo[0]), "+v"(bhi[0]), "+v"(blo[NJ - 1]), "+v"(bhi[NJ - 1]));
+        bf16x8 bfr[NJ];
+#pragma unroll
+        for (int jn = 0; jn < NJ; ++jn) bfr[jn] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(blo[jn], bhi[jn], 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bf16x8 af = __builtin_bit_cast(bf16x8, __builtin_shufflevector(alo[i], ahi[i], 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+            for (int jn = 0; jn < NJ; ++jn) acc[i][jn] = mfma_bf16_16x16x32(af, bfr[jn], acc[i][jn]);
+        }
+    };
+
+    issue(0); issue(1); issue(2);
+    for (int k = 0; k < nst; ++k) {
+        if (NB == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // stage k has landed; k+1, k+2 stay in flight
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                     // everyone's part of stage k is in LDS, everyone is done with slot (k+3) % 4
+        issue(k + 3);
+        compute(k);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS-DMA may outlive the workgroup
+
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int jn = 0; jn < NJ; ++jn) {
+            const int ncol = (wn * NJ + jn) * 16 + i16, kb = ncol >> 7, n = ncol & 127;
+            float* C = kb == 0 ? a.C : a.C2;
+            float* dst = nsplit == 1 ? C : a.partial + ((size_t)split * NB + kb) * a.M * a.N;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 128 + i * 16 + g * 4 + r;
+                dst[(size_t)m * a.N + n] = acc[i][jn][r];
+            }
+        }
+}
+
 struct Geo { int tiles_m, tiles_n, nsplit, rows_per_split; };
+bool v2_ok(const GemmTnArgsB& a) {
+    return a.M % V2_MT == 0 && a.N == 128 && a.lda == a.M && a.ldb == a.N && a.zeros != nullptr && !(a.drop_p > 0.f);
+}
+Geo geometry_v2(int R, int M) {
+    Geo g;
+    g.tiles_m = M / V2_MT; g.tiles_n = 1;
+    int nsplit = 256 / g.tiles_m;                         // one 512-thread workgroup per CU
+    const int max_split = ceil_div(R, 8 * V2_KC);
+    if (nsplit > max_split) nsplit = max_split;
+    if (nsplit < 1) nsplit = 1;
+    g.rows_per_split = round_up(ceil_div(R, nsplit), V2_KC);
+    g.nsplit = ceil_div(R, g.rows_per_split);
+    return g;
+}
 Geo geometry(int R, int M, int N, int NB) {
     Geo g;
     g.tiles_m = ceil_div(M, MT); g.tiles_n = ceil_div(N, NT);
@@ -155,7 +320,13 @@ Geo geometry(int R, int M, int N, int NB) {
 
 size_t gemm_tn_bf16_partial_elems(int R, int M, int N, int NB) {
     const Geo g = geometry(R, M, N, NB);
-    return g.nsplit > 1 ? (size_t)g.nsplit * NB * M * N : 0;
+    size_t e = g.nsplit > 1 ? (size_t)g.nsplit * NB * M * N : 0;
+    if (M % V2_MT == 0 && N == 128) {
+        const Geo g2 = geometry_v2(R, M);
+        const size_t e2 = g2.nsplit > 1 ? (size_t)g2.nsplit * NB * M * N : 0;
+        if (e2 > e) e = e2;
+    }
+    return e;
 }
 
 int launch_gemm_tn_bf16(const GemmTnArgsB& a, hipStream_t s) {
@@ -163,15 +334,31 @@ int launch_gemm_tn_bf16(const GemmTnArgsB& a, hipStream_t s) {
     SHM_REQUIRE((a.M & 7) == 0 && (a.N & 7) == 0 && (a.lda & 7) == 0 && (a.ldb & 7) == 0, SHM_EINVAL,
                 "gemm_tn_bf16: M, N, lda, ldb must be multiples of 8 (got %d %d %d %d)", a.M, a.N, a.lda, a.ldb);
     SHM_REQUIRE(a.NB == 1 || (a.Bm2 && a.C2), SHM_EINVAL, "gemm_tn_bf16: second operand missing");
-    const Geo g = geometry(a.R, a.M, a.N, a.NB);
+    const bool v2 = v2_ok(a);
+    const Geo g = v2 ? geometry_v2(a.R, a.M) : geometry(a.R, a.M, a.N, a.NB);
     SHM_REQUIRE(g.nsplit == 1 || (a.partial && a.partial_elems >= (size_t)g.nsplit * a.NB * a.M * a.N), SHM_EWORKSPACE,
                 "gemm_tn_bf16: split-K scratch too small");
-    const int tiles = g.tiles_m * g.tiles_n * a.NB;
-    const int grid = round_up(g.nsplit, 8) * tiles;
-    hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(grid), dim3(256), 0, s, a, g.tiles_m, g.tiles_n, g.rows_per_split, g.nsplit);
+    if (v2) {
+        const int grid = round_up(g.nsplit, 8) * g.tiles_m;
+        const size_t lds = (size_t)V2_NBUF * (V2_KC * V2_MT * 2 + V2_KC * 128 * a.NB * 2);
+        if (a.NB == 2) {
+            static bool attr2 = false;
+            if (!attr2) { SHM_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tn_bf16_v2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr2 = true; }
+            hipLaunchKernelGGL(gemm_tn_bf16_v2_kernel<2>, dim3(grid), dim3(512), lds, s, a, g.tiles_m, g.rows_per_split, g.nsplit);
+        } else {
+            static bool attr1 = false;
+            if (!attr1) { SHM_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tn_bf16_v2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr1 = true; }
+            hipLaunchKernelGGL(gemm_tn_bf16_v2_kernel<1>, dim3(grid), dim3(512), lds, s, a, g.tiles_m, g.rows_per_split, g.nsplit);
+        }
+    } else {
+        const int tiles = g.tiles_m * g.tiles_n * a.NB;
+        const int grid = round_up(g.nsplit, 8) * tiles;
+        hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(grid), dim3(256), 0, s, a, g.tiles_m, g.tiles_n, g.rows_per_split, g.nsplit);
+    }
     SHM_LAUNCH_CHECK();
     if (g.nsplit > 1) {
         // partial[split][kb][M*N]: reduce each product with a stride of NB*M*N between splits
+        if (a.NB == 2) return launch_reduce_partials_pair(a.partial, g.nsplit, (size_t)a.M * a.N, a.C, a.C2, s);
         for (int kb = 0; kb < a.NB; ++kb) {
             int rc = launch_reduce_partials_strided(a.partial + (size_t)kb * a.M * a.N, g.nsplit, (size_t)a.M * a.N, (size_t)a.NB * a.M * a.N,
                                                     kb == 0 ? a.C : a.C2, s);

@@ -99,6 +99,7 @@ size_t narrow_tn_scratch_elems(int M, int N);
 int launch_reduce_partials(const float* partial, int nparts, size_t n, float* out0, float* out1, hipStream_t s);
 // same with an explicit element stride between consecutive partials
 int launch_reduce_partials_strided(const float* partial, int nparts, size_t n, size_t stride, float* out0, hipStream_t s);
+int launch_reduce_partials_pair(const float* partial, int nparts, size_t n, float* outA, float* outB, hipStream_t s);   // partial[split][2][n]
 
 // ==== bf16 throughput path (fp32 accumulate / cell state / master weights) ===================================
 // Windows per workgroup of the recurrent kernels ("quad tiles", lstm_fwd_bf16.hip).  Sequence buffers of this path are
@@ -157,6 +158,7 @@ struct GemmTnArgsB {
     int shift_rows;
     float drop_p; uint64_t drop_seed; uint32_t drop_stack;     // dropout on product 0's B (element index r*N + n)
     float* partial; size_t partial_elems;
+    const void* zeros;             // >= 16 zero bytes (the H = 128 kernel reads them for rows that must contribute nothing); may be NULL
 };
 int launch_gemm_tn_bf16(const GemmTnArgsB& a, hipStream_t s);
 size_t gemm_tn_bf16_partial_elems(int R, int M, int N, int NB);

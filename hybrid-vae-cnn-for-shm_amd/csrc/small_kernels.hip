@@ -371,8 +371,9 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ A
 // block = 32 outputs x 8 partial-groups: group g sums partials g, g+8, ... (4 independent chains), then a fixed-order
 // combine over the groups — deterministic, and latency-tolerant even for few outputs and many partials.
 __global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __restrict__ partial, int nparts, size_t n_out, size_t n,
-                                                              float* __restrict__ out0, float* __restrict__ out1) {
+                                                              float* __restrict__ out0, float* __restrict__ out1, float* __restrict__ outB) {
     __shared__ float red[8][32];
+    if (blockIdx.y == 1) { partial += n_out; out0 = outB; out1 = nullptr; }     // second product of a shared-A GEMM
     const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const size_t i = (size_t)blockIdx.x * 32 + o;          // n = element stride between partials, n_out = outputs
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -610,15 +611,22 @@ int launch_vae_loss(int B, int T, int D, int Z, const float* x, const float* rec
 }
 size_t colsum_scratch_elems(int R, int N) { return (size_t)ceil_div(R, cs_rows(R)) * N; }
 int launch_reduce_partials(const float* partial, int nparts, size_t n, float* out0, float* out1, hipStream_t s) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, partial, nparts, n, n, out0, out1);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, partial, nparts, n, n, out0, out1, (float*)nullptr);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
 int launch_reduce_partials_strided(const float* partial, int nparts, size_t n, size_t stride, float* out0, hipStream_t s) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, partial, nparts, n, stride, out0, (float*)nullptr);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, partial, nparts, n, stride, out0, (float*)nullptr, (float*)nullptr);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
+// partial[split][2][n]: both products of a shared-A GEMM in one launch
+int launch_reduce_partials_pair(const float* partial, int nparts, size_t n, float* outA, float* outB, hipStream_t s) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 31) / 32), 2), dim3(256), 0, s, partial, nparts, n, 2 * n, outA, (float*)nullptr, outB);
+    SHM_LAUNCH_CHECK();
+    return SHM_OK;
+}
+
 int launch_colsum(const float* A, int lda, int R, int N, float* out0, float* out1, float* scratch, hipStream_t s) {
     const int chunks = ceil_div(R, cs_rows(R));
     hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 64), chunks), dim3(256), 0, s, A, lda, R, N, scratch);
