@@ -110,6 +110,7 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(int B, int H, int Z, int 
 #pragma unroll
             for (int i = 0; i < HMAX / 64; ++i) acc[r][i] = 0.f;
         const int mq = G / 4;
+#pragma unroll 8
         for (int m = w * mq; m < (w + 1) * mq; ++m) {
             float wv[HMAX / 64];
 #pragma unroll
@@ -200,8 +201,13 @@ __global__ void __launch_bounds__(256) head_grads_kernel(int B, int H, int Z, in
     }
     float s = 0.f;
     if (P) {
-        if (Q) for (int b = grp; b < B; b += 4) s = fmaf(P[(size_t)b * ldp + i], Q[(size_t)b * ldq + j], s);
-        else for (int b = grp; b < B; b += 4) s += P[(size_t)b * ldp + i];
+        if (Q) {
+#pragma unroll 8
+            for (int b = grp; b < B; b += 4) s = fmaf(P[(size_t)b * ldp + i], Q[(size_t)b * ldq + j], s);
+        } else {
+#pragma unroll 8
+            for (int b = grp; b < B; b += 4) s += P[(size_t)b * ldp + i];
+        }
     }
     red[grp][threadIdx.x & 63] = s;
     __syncthreads();
@@ -280,27 +286,37 @@ __global__ void __launch_bounds__(256) out_fwd_mfma_kernel(int B, int T, int D, 
     const int n_groups = (T * 4 + 15) / 16;                           // 16-row groups of this tile (4 steps each)
     const bf16_t* hb = h_seq + (size_t)tile * T * 4 * H;
     float sq[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int grp = w; grp < n_groups; grp += 4) {
-        const int row = grp * 16 + j;                                 // A operand row supplied by this lane
-        const bool rv = row < T * 4;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // GB groups per wave and pass: all their fragment loads (GB x KS x 16 B per lane) are in flight before the first MFMA
+    constexpr int GB = 4;
+    const bf16x8 zero8 = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+    for (int g0 = w * GB; g0 < n_groups; g0 += 4 * GB) {
+        bf16x8 af[GB][KS];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            bf16x8 af = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
-            if (rv) af = *reinterpret_cast<const bf16x8*>(hb + (size_t)row * H + 8 * q + 32 * s);
-            acc = mfma_bf16_16x16x32(af, wf[s], acc);
+        for (int gi = 0; gi < GB; ++gi) {
+            const int row = (g0 + gi) * 16 + j;                       // A operand row supplied by this lane
+            const bool rv = row < T * 4;
+            const bf16_t* src = hb + (size_t)(rv ? row : 0) * H + 8 * q;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) { const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + 32 * s); af[gi][s] = rv ? v : zero8; }
         }
-        const int t = grp * 4 + q;                                    // accumulator rows 4q + r: step t, window r
-        if (j < D && t < T) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int b = tile * 4 + r;
-                if (b < B) {
-                    const size_t o = ((size_t)b * T + t) * D + j;
-                    const float rc = acc[r] + bias;
-                    if (recon) recon[o] = rc;
-                    const float e = x[o] - rc;
-                    sq[r] = fmaf(e, e, sq[r]);
+        for (int gi = 0; gi < GB; ++gi) {
+            const int grp = g0 + gi;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) acc = mfma_bf16_16x16x32(af[gi][s], wf[s], acc);
+            const int t = grp * 4 + q;                                // accumulator rows 4q + r: step t, window r
+            if (j < D && t < T) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int b = tile * 4 + r;
+                    if (b < B) {
+                        const size_t o = ((size_t)b * T + t) * D + j;
+                        const float rc = acc[r] + bias;
+                        if (recon) recon[o] = rc;
+                        const float e = x[o] - rc;
+                        sq[r] = fmaf(e, e, sq[r]);
+                    }
                 }
             }
         }
@@ -431,20 +447,24 @@ __global__ void __launch_bounds__(256) narrow_tn_kernel(const TA* __restrict__ A
     }
     const int stride = N * M + (with_bsum ? N : 0);      // floats per block partial
     if (grp < groups) {
-#pragma unroll 2
+        // branch-free body (padding windows read row 0 and are multiplied by zero) so that the unrolled loads of several
+        // rows are all in flight together: the kernel is a pure stream over A
+#pragma unroll 8
         for (int r = r0 + grp; r < r1; r += groups) {
             size_t rb = (size_t)r;                        // row of Bn that pairs with row r of A
+            float keep = 1.f;
             if (tile_T > 0) {
                 const int blk = r / SHM_WPT, tl = blk / tile_T, tt = blk - tl * tile_T, bb = tl * SHM_WPT + (r - blk * SHM_WPT);
-                if (bb >= tile_B) continue;               // padding window
-                rb = (size_t)bb * tile_T + tt;
+                const bool ok = bb < tile_B;              // else: padding window
+                rb = ok ? (size_t)bb * tile_T + tt : 0;
+                keep = ok ? 1.f : 0.f;
             }
             float av[CPT];
             VecLoad<TA, CPT>::ld(A + (size_t)r * lda + m, av);
 #pragma unroll
             for (int n = 0; n < NMAX; ++n) {
                 if (n < N) {
-                    const float bv = Bn[rb * N + n];
+                    const float bv = Bn[rb * N + n] * keep;
                     bs[n] += bv;
 #pragma unroll
                     for (int c = 0; c < CPT; ++c) acc[n][c] = fmaf(bv, av[c], acc[n][c]);
