@@ -60,9 +60,11 @@ struct shm_vae_plan {
     // workspace byte offsets
     size_t h_last, eps, y, xhat, rstd, mu, lv, z, h0, dpre_l2h, dmu, dlv, dyx, dy, dh_last, dh0;
     size_t recon, score, d_recon, d_mu, d_lv, dpre_seq, dx_seq, dpre_tsum, gemm_partial, colsum_scratch;
+    size_t gemm_partial_b, gemm_partial_c;   // bf16 pair path: split-K scratch of the layer-0 GEMM / the fp32 dec0 dW_ih GEMM (all reduced in one batch)
     size_t dpre_seq2, dpre_tsum2;   // bf16 path, 2 layers: the top layer's dpre / sum_t dpre (both layers' live at once in a pair launch)
     size_t gemm_partial_elems;
-    size_t narrow_scratch;  // block partials of narrow_tn
+    size_t narrow_scratch;  // block partials of narrow_tn (enc0 dW_ih)
+    size_t narrow_scratch2; // block partials of narrow_tn (dW_out): both may be pending in one reduce batch
     size_t pair_sync;       // bf16 path, 2 layers: ticket / progress words of the layer-pipelined launches (zeroed per launch)
     size_t misc;            // bf16 path: [64 B sticky error word of the pair launches][256 zero bytes], zeroed by pack_weights
     size_t params_copy;     // flat fp32 copy of the parameters (head / output layer read them unpacked)
@@ -263,7 +265,14 @@ extern "C" int shm_vae_plan_create(const shm_vae_config* cfg, int32_t B, int32_t
         }
         p->gemm_partial_elems = gp;
         p->narrow_scratch = take(narrow_tn_scratch_elems(4 * H, D));
+        p->narrow_scratch2 = take(narrow_tn_scratch_elems(H, D));
         p->gemm_partial = take(gp > 0 ? gp : 1);
+        if (bf && L == 2) {
+            const size_t eb = gemm_tn_bf16_partial_elems((int)(qt * SHM_WPT * T), 4 * H, H, 1);
+            p->gemm_partial_b = take(eb > 0 ? eb : 1);
+            const size_t ec = gemm_tn_partial_elems(B, 4 * H, H);
+            p->gemm_partial_c = take(ec > 0 ? ec : 1);
+        }
         size_t cs = colsum_scratch_elems((int)BT, D);
         const size_t cs2 = colsum_scratch_elems(B, 4 * H);
         if (cs2 > cs) cs = cs2;
@@ -479,34 +488,38 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
 
     const bool bf = c.precision == SHM_PREC_BF16;
     // wide products on bf16 operands: dW_ih = dpre^T x_in (dropout re-applied) and dW_hh = dpre^T h_{t-1} in ONE launch (A read once)
-    auto gemm_bf = [&](const void* A, int M, const void* Bin, float* Cin, float dp, uint32_t stack, const void* Bh, float* Chh, int R) -> int {
+    auto gemm_bf = [&](const void* A, int M, const void* Bin, float* Cin, float dp, uint32_t stack, const void* Bh, float* Chh, int R,
+                       ReduceJobs* defer = nullptr, float* part = nullptr) -> int {
         GemmTnArgsB g;
         memset(&g, 0, sizeof(g));
         g.A = A; g.lda = M; g.ldb = H; g.R = R; g.M = M; g.N = H; g.shift_rows = SHM_WPT;
         if (Bin) { g.NB = 2; g.Bm = Bin; g.C = Cin; g.shift_T = 0; g.Bm2 = Bh; g.C2 = Chh; g.shift_T2 = T; }
         else { g.NB = 1; g.Bm = Bh; g.C = Chh; g.shift_T = T; }
         g.drop_p = dp; g.drop_seed = p->drop_seed; g.drop_stack = stack;
-        g.partial = at<float>(ws, p->gemm_partial); g.partial_elems = p->gemm_partial_elems;
+        g.partial = part ? part : at<float>(ws, p->gemm_partial); g.partial_elems = p->gemm_partial_elems;
         g.zeros = at<char>(ws, p->misc + 64);
-        return launch_gemm_tn_bf16(g, s);
+        return launch_gemm_tn_bf16(g, s, defer);
     };
     auto gemm = [&](const void* A, int lda, int M, const void* Bm, int ldb, int N, int R, float* C, int shift_T, int trans_out,
-                    float dp, uint32_t stack, int a_bf16 = 0, int b_bf16 = 0) -> int {
+                    float dp, uint32_t stack, int a_bf16 = 0, int b_bf16 = 0, ReduceJobs* defer = nullptr, float* part = nullptr) -> int {
         GemmTnArgs g;
         memset(&g, 0, sizeof(g));
         g.a_bf16 = a_bf16; g.b_bf16 = b_bf16;
         g.A = A; g.lda = lda; g.Bm = Bm; g.ldb = ldb; g.C = C; g.ldc = trans_out ? M : N; g.R = R; g.M = M; g.N = N;
         g.shift_T = shift_T; g.trans_out = trans_out; g.drop_p = dp; g.drop_seed = p->drop_seed; g.drop_stack = stack;
-        g.partial = at<float>(ws, p->gemm_partial); g.partial_elems = p->gemm_partial_elems;
-        return launch_gemm_tn_f32(g, s);
+        g.partial = part ? part : at<float>(ws, p->gemm_partial); g.partial_elems = p->gemm_partial_elems;
+        return launch_gemm_tn_f32(g, s, defer);
     };
 
     // output layer (temporal_vae.py:70): dW_out[d][k] = sum_r d_recon[r][d] h[r][k]
     const void* h_top = at<char>(ws, p->dec[L - 1].h_seq);
+    const bool pair_bwd = bf && L == 2 && pair_launch_enabled();
+    ReduceJobs rjobs;                    // pair path: every reduction of a stack in ONE launch at the end of the stack
+    rjobs.n = 0;
     {
         KernelTimer kt("dw_gemm.out", s);
         if ((rc = launch_narrow_tn(h_top, bf ? 1 : 0, H, H, d_recon, D, bf ? ceil_div(B, SHM_WPT) * SHM_WPT * T : BT, grads + p->out_w, 0, grads + p->out_b,
-                                   at<float>(ws, p->narrow_scratch), s, bf ? T : 0, bf ? B : 0))) return rc;
+                                   at<float>(ws, p->narrow_scratch2), s, bf ? T : 0, bf ? B : 0, pair_bwd ? &rjobs : nullptr))) return rc;
     }
 
     auto run_stack_bwd = [&](LayerInst* st, uint32_t stack, const float* x0, bool is_dec) -> int {
@@ -530,19 +543,22 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
             return a;
         };
         // deferred weight / bias gradients of layer l from its stored dpre sequence
-        auto layer_grads_bf = [&](int l, const void* dps, const float* tsum) -> int {
+        auto layer_grads_bf = [&](int l, const void* dps, const float* tsum, ReduceJobs* defer = nullptr) -> int {
             int r;
+            float* part = defer ? at<float>(ws, l > 0 ? p->gemm_partial : p->gemm_partial_b) : nullptr;
             if (l > 0) {      // with dropout the forward left the masked input in xdrop: no re-hashing in the GEMM
                 const void* xin = drop > 0.f ? at<char>(ws, st[l].xdrop) : at<char>(ws, st[l - 1].h_seq);
-                if ((r = gemm_bf(dps, G, xin, grads + st[l].w_ih, 0.f, stack, at<char>(ws, st[l].h_seq), grads + st[l].w_hh, Rt))) return r;
-            } else if ((r = gemm_bf(dps, G, nullptr, nullptr, 0.f, 0, at<char>(ws, st[l].h_seq), grads + st[l].w_hh, Rt))) return r;
+                if ((r = gemm_bf(dps, G, xin, grads + st[l].w_ih, 0.f, stack, at<char>(ws, st[l].h_seq), grads + st[l].w_hh, Rt, defer, part))) return r;
+            } else if ((r = gemm_bf(dps, G, nullptr, nullptr, 0.f, 0, at<char>(ws, st[l].h_seq), grads + st[l].w_hh, Rt, defer, part))) return r;
             if (l > 0) {
             } else if (st[l].in_const) {
-                if ((r = gemm(tsum, G, G, hb.h0, H, H, B, grads + st[l].w_ih, 0, 0, 0.f, 0))) return r;
+                if ((r = gemm(tsum, G, G, hb.h0, H, H, B, grads + st[l].w_ih, 0, 0, 0.f, 0, 0, 0, defer, defer ? at<float>(ws, p->gemm_partial_c) : nullptr))) return r;
             } else {
-                if ((r = launch_narrow_tn(dps, 1, G, G, x0, D, Rt, grads + st[l].w_ih, 1, nullptr, at<float>(ws, p->narrow_scratch), s, T, B))) return r;
+                if ((r = launch_narrow_tn(dps, 1, G, G, x0, D, Rt, grads + st[l].w_ih, 1, nullptr, at<float>(ws, p->narrow_scratch), s, T, B, defer))) return r;
             }
-            return launch_colsum(tsum, G, B, G, grads + st[l].b_ih, grads + st[l].b_hh, cs, s);
+            // bias grads = column sums of sum_t dpre over the B windows: the same fixed-order reduction, batched or not
+            if (defer) return reduce_jobs_add(*defer, tsum, B, (size_t)G, (size_t)G, grads + st[l].b_ih, grads + st[l].b_hh);
+            return launch_reduce_partials(tsum, B, (size_t)G, grads + st[l].b_ih, grads + st[l].b_hh, s);
         };
         if (bf && L == 2 && pair_launch_enabled()) {
             // both layers in one launch (layer 0 forms dx itself, a few steps behind layer 1); layer 0 keeps the primary
@@ -559,10 +575,11 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
             if (r) return r;
             {
                 KernelTimer kt(stack == 0 ? "dw_gemm.enc1" : "dw_gemm.dec1", s);
-                if ((r = layer_grads_bf(1, dps1, tsum1))) return r;
+                if ((r = layer_grads_bf(1, dps1, tsum1, &rjobs))) return r;
             }
             KernelTimer kt(stack == 0 ? "dw_gemm.enc0" : "dw_gemm.dec0", s);
-            return layer_grads_bf(0, at<char>(ws, p->dpre_seq), dpre_tsum);
+            if ((r = layer_grads_bf(0, at<char>(ws, p->dpre_seq), dpre_tsum, &rjobs))) return r;
+            return launch_reduce_batch(rjobs, s);
         }
         for (int l = L - 1; l >= 0; --l) {
             char nm[32], gnm[32];

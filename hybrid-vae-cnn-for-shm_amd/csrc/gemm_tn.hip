@@ -127,7 +127,7 @@ size_t gemm_tn_partial_elems(int R, int M, int N) {
     return g.nsplit > 1 ? (size_t)g.nsplit * M * N : 0;
 }
 
-int launch_gemm_tn_f32(const GemmTnArgs& a, hipStream_t s) {
+int launch_gemm_tn_f32(const GemmTnArgs& a, hipStream_t s, ReduceJobs* defer) {
     SHM_REQUIRE(a.R > 0 && a.M > 0 && a.N > 0, SHM_EINVAL, "gemm_tn: empty shape R=%d M=%d N=%d", a.R, a.M, a.N);
     const Geo g = geometry(a.R, a.M, a.N);
     SHM_REQUIRE(g.nsplit == 1 || (a.partial && a.partial_elems >= (size_t)g.nsplit * a.M * a.N), SHM_EWORKSPACE,
@@ -147,7 +147,10 @@ int launch_gemm_tn_f32(const GemmTnArgs& a, hipStream_t s) {
     else SHM_GEMM_LAUNCH(float, float);
 #undef SHM_GEMM_LAUNCH
     SHM_LAUNCH_CHECK();
-    if (g.nsplit > 1) return launch_reduce_partials(a.partial, g.nsplit, (size_t)a.M * a.N, a.C, nullptr, s);
+    if (g.nsplit > 1) {
+        if (defer) return reduce_jobs_add(*defer, a.partial, g.nsplit, (size_t)a.M * a.N, (size_t)a.M * a.N, a.C, nullptr);
+        return launch_reduce_partials(a.partial, g.nsplit, (size_t)a.M * a.N, a.C, nullptr, s);
+    }
     return SHM_OK;
 }
 

@@ -329,7 +329,7 @@ size_t gemm_tn_bf16_partial_elems(int R, int M, int N, int NB) {
     return e;
 }
 
-int launch_gemm_tn_bf16(const GemmTnArgsB& a, hipStream_t s) {
+int launch_gemm_tn_bf16(const GemmTnArgsB& a, hipStream_t s, ReduceJobs* defer) {
     SHM_REQUIRE(a.R > 0 && a.M > 0 && a.N > 0 && (a.NB == 1 || a.NB == 2), SHM_EINVAL, "gemm_tn_bf16: bad shape");
     SHM_REQUIRE((a.M & 7) == 0 && (a.N & 7) == 0 && (a.lda & 7) == 0 && (a.ldb & 7) == 0, SHM_EINVAL,
                 "gemm_tn_bf16: M, N, lda, ldb must be multiples of 8 (got %d %d %d %d)", a.M, a.N, a.lda, a.ldb);
@@ -358,6 +358,14 @@ int launch_gemm_tn_bf16(const GemmTnArgsB& a, hipStream_t s) {
     SHM_LAUNCH_CHECK();
     if (g.nsplit > 1) {
         // partial[split][kb][M*N]: reduce each product with a stride of NB*M*N between splits
+        if (defer) {
+            for (int kb = 0; kb < a.NB; ++kb) {
+                int rc = reduce_jobs_add(*defer, a.partial + (size_t)kb * a.M * a.N, g.nsplit, (size_t)a.M * a.N, (size_t)a.NB * a.M * a.N,
+                                         kb == 0 ? a.C : a.C2, nullptr);
+                if (rc) return rc;
+            }
+            return SHM_OK;
+        }
         if (a.NB == 2) return launch_reduce_partials_pair(a.partial, g.nsplit, (size_t)a.M * a.N, a.C, a.C2, s);
         for (int kb = 0; kb < a.NB; ++kb) {
             int rc = launch_reduce_partials_strided(a.partial + (size_t)kb * a.M * a.N, g.nsplit, (size_t)a.M * a.N, (size_t)a.NB * a.M * a.N,

@@ -83,7 +83,18 @@ struct GemmTnArgs {
     float* partial;                // split-K scratch
     size_t partial_elems;
 };
-int launch_gemm_tn_f32(const GemmTnArgs& a, hipStream_t s);
+// Deferred split-K / block-partial reductions: launchers that are handed a ReduceJobs append their reduction instead of
+// launching it; launch_reduce_batch then reduces every appended job in ONE launch (each job keeps its own scratch until then).
+struct ReduceJob {
+    const float* partial; int nparts; unsigned n_out; size_t stride;   // out[i] = sum_p partial[p*stride + i], fixed order
+    float* out0; float* out1;                                          // out1 optional (same values)
+    int tr_M;                                                          // > 0: element i = n*tr_M + m is written to out0[m*(n_out/tr_M) + n]
+};
+constexpr int MAX_REDUCE_JOBS = 12;
+struct ReduceJobs { ReduceJob job[MAX_REDUCE_JOBS]; int first_block[MAX_REDUCE_JOBS + 1]; int n; };
+int reduce_jobs_add(ReduceJobs& j, const float* partial, int nparts, size_t n_out, size_t stride, float* out0, float* out1, int tr_M = 0);
+int launch_reduce_batch(ReduceJobs& jobs, hipStream_t s);
+int launch_gemm_tn_f32(const GemmTnArgs& a, hipStream_t s, ReduceJobs* defer = nullptr);
 size_t gemm_tn_partial_elems(int R, int M, int N);
 // out[n] = sum_r A[r*lda + n], written to out0 and (if non-null) out1; scratch: colsum_scratch_elems(R,N) floats
 int launch_colsum(const float* A, int lda, int R, int N, float* out0, float* out1, float* scratch, hipStream_t s);
@@ -93,7 +104,7 @@ size_t colsum_scratch_elems(int R, int N);
 // tile_T > 0: A's rows are tile-blocked (row r' = (tile*tile_T + t)*16 + j) while Bn is natural [B, tile_T, N]; rows of windows
 // >= tile_B are padding and skipped.
 int launch_narrow_tn(const void* A, int a_bf16, int lda, int M, const float* Bn, int N, int R, float* out, int trans_out,
-                     float* bsum_out, float* scratch, hipStream_t s, int tile_T = 0, int tile_B = 0);
+                     float* bsum_out, float* scratch, hipStream_t s, int tile_T = 0, int tile_B = 0, ReduceJobs* defer = nullptr);
 size_t narrow_tn_scratch_elems(int M, int N);
 // out[i] (and out1[i]) = sum_p partial[p*n + i], p < nparts (fixed order)
 int launch_reduce_partials(const float* partial, int nparts, size_t n, float* out0, float* out1, hipStream_t s);
@@ -160,7 +171,7 @@ struct GemmTnArgsB {
     float* partial; size_t partial_elems;
     const void* zeros;             // >= 16 zero bytes (the H = 128 kernel reads them for rows that must contribute nothing); may be NULL
 };
-int launch_gemm_tn_bf16(const GemmTnArgsB& a, hipStream_t s);
+int launch_gemm_tn_bf16(const GemmTnArgsB& a, hipStream_t s, ReduceJobs* defer = nullptr);
 size_t gemm_tn_bf16_partial_elems(int R, int M, int N, int NB);
 
 // all bf16 re-layouts + bias sums of one parameter update in a single launch

@@ -412,6 +412,38 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __res
     }
 }
 
+// every deferred reduction of a backward stage in one launch: block -> (job, 32 outputs) through the prefix table
+__global__ void __launch_bounds__(256) reduce_batch_kernel(ReduceJobs jobs) {
+    __shared__ float red[8][32];
+    int j = 0;
+    while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.first_block[j + 1]) ++j;
+    const ReduceJob jb = jobs.job[j];
+    const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const size_t i = (size_t)(blockIdx.x - jobs.first_block[j]) * 32 + o;
+    const float* __restrict__ partial = jb.partial;
+    const size_t n = jb.stride;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < jb.n_out) {
+        int p = grp;
+        for (; p + 24 < jb.nparts; p += 32) {
+            s0 += partial[(size_t)p * n + i];
+            s1 += partial[(size_t)(p + 8) * n + i];
+            s2 += partial[(size_t)(p + 16) * n + i];
+            s3 += partial[(size_t)(p + 24) * n + i];
+        }
+        for (; p < jb.nparts; p += 8) s0 += partial[(size_t)p * n + i];
+    }
+    red[grp][o] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (grp == 0 && i < jb.n_out) {
+        const float v = ((red[0][o] + red[1][o]) + (red[2][o] + red[3][o])) + ((red[4][o] + red[5][o]) + (red[6][o] + red[7][o]));
+        size_t dst = i;
+        if (jb.tr_M > 0) { const size_t nn = i / jb.tr_M, mm = i - nn * jb.tr_M; dst = mm * (jb.n_out / jb.tr_M) + nn; }
+        jb.out0[dst] = v;
+        if (jb.out1) jb.out1[dst] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ narrow TN product
 // out[n][m] = sum_r Bn[r][n] * A[r][m]  with n < N <= 16 (channel count): dW_out = d_recon^T h_top, dW_ih(enc0) = dpre^T x.
 // A is streamed once (HBM-bound, 2 columns per thread); Bn is a broadcast load.  Block partials -> reduce_partials.
@@ -640,6 +672,22 @@ int launch_reduce_partials_strided(const float* partial, int nparts, size_t n, s
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
+int reduce_jobs_add(ReduceJobs& j, const float* partial, int nparts, size_t n_out, size_t stride, float* out0, float* out1, int tr_M) {
+    SHM_REQUIRE(j.n < MAX_REDUCE_JOBS, SHM_EINVAL, "reduce batch: more than %d jobs", MAX_REDUCE_JOBS);
+    ReduceJob& r = j.job[j.n++];
+    r.partial = partial; r.nparts = nparts; r.n_out = (unsigned)n_out; r.stride = stride; r.out0 = out0; r.out1 = out1; r.tr_M = tr_M;
+    return SHM_OK;
+}
+int launch_reduce_batch(ReduceJobs& jobs, hipStream_t s) {
+    if (jobs.n == 0) return SHM_OK;
+    int blocks = 0;
+    for (int i = 0; i < jobs.n; ++i) { jobs.first_block[i] = blocks; blocks += (int)((jobs.job[i].n_out + 31) / 32); }
+    jobs.first_block[jobs.n] = blocks;
+    hipLaunchKernelGGL(reduce_batch_kernel, dim3(blocks), dim3(256), 0, s, jobs);
+    SHM_LAUNCH_CHECK();
+    jobs.n = 0;
+    return SHM_OK;
+}
 // partial[split][2][n]: both products of a shared-A GEMM in one launch
 int launch_reduce_partials_pair(const float* partial, int nparts, size_t n, float* outA, float* outB, hipStream_t s) {
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 31) / 32), 2), dim3(256), 0, s, partial, nparts, n, 2 * n, outA, (float*)nullptr, outB);
@@ -667,7 +715,7 @@ int launch_pack_bwd_f32(const float* W, int H, int M, float* dst, hipStream_t s)
 }
 size_t narrow_tn_scratch_elems(int M, int N) { return (size_t)(NARROW_BLOCKS + 1) * (M * N + N); }
 int launch_narrow_tn(const void* A, int a_bf16, int lda, int M, const float* Bn, int N, int R, float* out, int trans_out,
-                     float* bsum_out, float* scratch, hipStream_t s, int tile_T, int tile_B) {
+                     float* bsum_out, float* scratch, hipStream_t s, int tile_T, int tile_B, ReduceJobs* defer) {
     const int cpt = N <= 4 ? 8 : 2, nmax = N <= 4 ? 4 : 16;
     SHM_REQUIRE(N >= 1 && N <= 16 && M >= cpt && M <= 512 && M % cpt == 0 && 256 % (M / cpt) == 0 && lda % cpt == 0, SHM_EINVAL,
                 "narrow_tn: unsupported shape M=%d N=%d lda=%d", M, N, lda);
@@ -682,6 +730,11 @@ int launch_narrow_tn(const void* A, int a_bf16, int lda, int M, const float* Bn,
     else { if (nmax == 4) SHM_NARROW(float, 4, 8); else SHM_NARROW(float, 16, 2); }
 #undef SHM_NARROW
     SHM_LAUNCH_CHECK();
+    if (defer) {       // straight into the outputs, later, together with the other reductions of the stage
+        int rc = reduce_jobs_add(*defer, scratch, blocks, (size_t)M * N, stride, out, nullptr, trans_out ? M : 0);
+        if (!rc && wb) rc = reduce_jobs_add(*defer, scratch + (size_t)M * N, blocks, (size_t)N, stride, bsum_out, nullptr);
+        return rc;
+    }
     float* red = scratch + (size_t)blocks * stride;          // [N*M (+N)] reduced
     int rc = launch_reduce_partials(scratch, blocks, stride, red, nullptr, s);
     if (rc) return rc;
