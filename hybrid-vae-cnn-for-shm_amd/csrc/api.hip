@@ -66,6 +66,7 @@ struct shm_vae_plan {
     size_t narrow_scratch;  // block partials of narrow_tn (enc0 dW_ih)
     size_t narrow_scratch2; // block partials of narrow_tn (dW_out): both may be pending in one reduce batch
     size_t pair_sync;       // bf16 path, 2 layers: ticket / progress words of the layer-pipelined launches (zeroed per launch)
+    size_t x_tb;            // bf16 path: tile-blocked bf16 copy of x [Rq, 16], written by encoder layer 0's forward, read by its dW_ih product
     size_t misc;            // bf16 path: [64 B sticky error word of the pair launches][256 zero bytes], zeroed by pack_weights
     size_t params_copy;     // flat fp32 copy of the parameters (head / output layer read them unpacked)
     size_t ws_bytes;
@@ -244,6 +245,7 @@ extern "C" int shm_vae_plan_create(const shm_vae_config* cfg, int32_t B, int32_t
     }
     if (bf && L == 2) p->pair_sync = take_bytes(lstm_fwd_pair_sync_bytes(B));
     if (bf) p->misc = take_bytes(64 + 256);
+    if (bf) p->x_tb = take_bytes(2 * Rq * 16);
     p->params_copy = take((size_t)p->n_params);
     p->h_last = take((size_t)B * H); p->eps = take((size_t)B * Z);
     p->y = take((size_t)B * H); p->xhat = take((size_t)B * H); p->rstd = take(B);
@@ -376,6 +378,7 @@ extern "C" int shm_vae_forward(shm_vae_plan* p, const float* x, const float* eps
             a.h_last = (l == L - 1) ? h_last : nullptr;
             a.sv_g = save ? at<bf16_t>(ws, st[l].saved) : nullptr;
             a.xdrop = (l > 0 && c.dropout > 0.f) ? at<bf16_t>(ws, st[l].xdrop) : nullptr;
+            a.x_tb = (l == 0 && !st[l].in_const) ? at<bf16_t>(ws, p->x_tb) : nullptr;
             a.B = B; a.T = T; a.In = st[l].In; a.in_const = st[l].in_const ? 1 : 0;
             a.drop_p = l > 0 ? drop : 0.f; a.drop_seed = drop_seed; a.drop_stack = stack;
             return a;
@@ -489,9 +492,10 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
     const bool bf = c.precision == SHM_PREC_BF16;
     // wide products on bf16 operands: dW_ih = dpre^T x_in (dropout re-applied) and dW_hh = dpre^T h_{t-1} in ONE launch (A read once)
     auto gemm_bf = [&](const void* A, int M, const void* Bin, float* Cin, float dp, uint32_t stack, const void* Bh, float* Chh, int R,
-                       ReduceJobs* defer = nullptr, float* part = nullptr) -> int {
+                       ReduceJobs* defer = nullptr, float* part = nullptr, const void* Bx = nullptr, float* Cx = nullptr) -> int {
         GemmTnArgsB g;
         memset(&g, 0, sizeof(g));
+        g.Bx = Bx; g.Cx = Cx; g.Nx = D;
         g.A = A; g.lda = M; g.ldb = H; g.R = R; g.M = M; g.N = H; g.shift_rows = SHM_WPT;
         if (Bin) { g.NB = 2; g.Bm = Bin; g.C = Cin; g.shift_T = 0; g.Bm2 = Bh; g.C2 = Chh; g.shift_T2 = T; }
         else { g.NB = 1; g.Bm = Bh; g.C = Chh; g.shift_T = T; }
@@ -549,13 +553,20 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
             if (l > 0) {      // with dropout the forward left the masked input in xdrop: no re-hashing in the GEMM
                 const void* xin = drop > 0.f ? at<char>(ws, st[l].xdrop) : at<char>(ws, st[l - 1].h_seq);
                 if ((r = gemm_bf(dps, G, xin, grads + st[l].w_ih, 0.f, stack, at<char>(ws, st[l].h_seq), grads + st[l].w_hh, Rt, defer, part))) return r;
-            } else if ((r = gemm_bf(dps, G, nullptr, nullptr, 0.f, 0, at<char>(ws, st[l].h_seq), grads + st[l].w_hh, Rt, defer, part))) return r;
+            } else {
+                // fp32-input layer at H = 128: dW_ih = dpre^T bf16(x) rides along as a 16-column third product (A is read once)
+                const bool xfuse = !st[l].in_const && H == 128;
+                if ((r = gemm_bf(dps, G, nullptr, nullptr, 0.f, 0, at<char>(ws, st[l].h_seq), grads + st[l].w_hh, Rt, defer, part,
+                                 xfuse ? at<char>(ws, p->x_tb) : nullptr, xfuse ? grads + st[l].w_ih : nullptr))) return r;
+                if (xfuse) goto bias;
+            }
             if (l > 0) {
             } else if (st[l].in_const) {
                 if ((r = gemm(tsum, G, G, hb.h0, H, H, B, grads + st[l].w_ih, 0, 0, 0.f, 0, 0, 0, defer, defer ? at<float>(ws, p->gemm_partial_c) : nullptr))) return r;
             } else {
                 if ((r = launch_narrow_tn(dps, 1, G, G, x0, D, Rt, grads + st[l].w_ih, 1, nullptr, at<float>(ws, p->narrow_scratch), s, T, B, defer))) return r;
             }
+        bias:
             // bias grads = column sums of sum_t dpre over the B windows: the same fixed-order reduction, batched or not
             if (defer) return reduce_jobs_add(*defer, tsum, B, (size_t)G, (size_t)G, grads + st[l].b_ih, grads + st[l].b_hh);
             return launch_reduce_partials(tsum, B, (size_t)G, grads + st[l].b_ih, grads + st[l].b_hh, s);

@@ -155,10 +155,12 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_cvoid;
 __device__ __forceinline__ int v2_swz(int r) { return (((r >> 3) & 1) << 2) | (r & 3); }
 
-template <int NB>
+// XP: a third, 16-column product sharing A (dW_ih of the fp32-input layer: Bx = the tile-blocked bf16 copy of x)
+template <int NB, bool XP>
 __global__ void __launch_bounds__(512) gemm_tn_bf16_v2_kernel(GemmTnArgsB a, int tiles_m, int rows_per_split, int nsplit) {
     constexpr int NT = 128 * NB;                         // B image row: [product 0 | product 1]
-    constexpr int A_BYTES = V2_KC * V2_MT * 2, B_BYTES = V2_KC * NT * 2, ST_BYTES = A_BYTES + B_BYTES;
+    constexpr int A_BYTES = V2_KC * V2_MT * 2, B_BYTES = V2_KC * NT * 2, X_BYTES = XP ? V2_KC * 16 * 2 : 0;
+    constexpr int ST_BYTES = A_BYTES + B_BYTES + X_BYTES;
     constexpr int GL_A = 2, GL_B = NB;                   // LDS-DMA instructions per wave and stage
     constexpr int NJ = 2 * NB;                           // 16-column MFMA tiles per wave along N (wave tile 128 x 32*NB)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -213,13 +215,22 @@ __global__ void __launch_bounds__(512) gemm_tn_bf16_v2_kernel(GemmTnArgsB a, int
             const bf16_t* src = ok ? base + (size_t)rr * a.ldb + b_col[i] : zeros;
             __builtin_amdgcn_global_load_lds((gbl_cvoid*)src, (lds_void*)(buf + A_BYTES + ((NB == 2 ? 2 * w : 0) + (NB == 2 ? i : w)) * 1024), 16, 0, 0);
         }
+        if constexpr (XP) {
+            if (w == 0) {                                 // 32 rows x 32 B: lane -> row l>>1, half l&1
+                const int r = r0 + (lane >> 1);
+                const bf16_t* src = r < r_end ? reinterpret_cast<const bf16_t*>(a.Bx) + (size_t)r * 16 + (lane & 1) * 8 : zeros;
+                __builtin_amdgcn_global_load_lds((gbl_cvoid*)src, (lds_void*)(buf + A_BYTES + B_BYTES), 16, 0, 0);
+            }
+        }
     };
 
-    f32x4 acc[8][NJ];
+    f32x4 acc[8][NJ], accx[XP ? 8 : 1];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int jn = 0; jn < NJ; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < (XP ? 8 : 1); ++i) accx[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // transpose reads: lane (g, qq, pp) supplies row 8g + qq (+4), columns 4pp..4pp+3 of a 16-column block.
     // The reads are inline asm: for a compiler-visible ds_read hipcc waits vmcnt(0) while any LDS-DMA is in flight (it cannot
@@ -233,7 +244,10 @@ __global__ void __launch_bounds__(512) gemm_tn_bf16_v2_kernel(GemmTnArgsB a, int
     for (int jn = 0; jn < NJ; ++jn) b_off[jn] = A_BYTES + tr_r * (NT * 2) + (((wn * NJ + jn) ^ fz) << 5) + pp * 8;
     auto compute = [&](int k) {
         const uint32_t buf = lds0 + (k & (V2_NBUF - 1)) * ST_BYTES;
-        s16x4 alo[8], ahi[8], blo[NJ], bhi[NJ];
+        s16x4 alo[8], ahi[8], blo[NJ], bhi[NJ], xlo = {0, 0, 0, 0}, xhi = {0, 0, 0, 0};
+        if constexpr (XP)
+            asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:128"
+                         : "=&v"(xlo), "=&v"(xhi) : "v"(buf + A_BYTES + B_BYTES + tr_r * 32 + pp * 8));
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3"
@@ -251,7 +265,7 @@ __global__ void __launch_bounds__(512) gemm_tn_bf16_v2_kernel(GemmTnArgsB a, int
             asm volatile("s_waitcnt lgkmcnt(0)"
                          : "+v"(alo[0]), "+v"(ahi[0]), "+v"(alo[1]), "+v"(ahi[1]), "+v"(alo[2]), "+v"(ahi[2]), "+v"(alo[3]), "+v"(ahi[3]),
                            "+v"(alo[4]), "+v"(ahi[4]), "+v"(alo[5]), "+v"(ahi[5]), "+v"(alo[6]), "+v"(ahi[6]), "+v"(alo[7]), "+v"(ahi[7]),
-                           "+v"(blo[0]), "+v"(bhi[0]), "+v"(blo[NJ - 1]), "+v"(bhi[NJ - 1]));
+                           "+v"(blo[0]), "+v"(bhi[0]), "+v"(blo[NJ - 1]), "+v"(bhi[NJ - 1]), "+v"(xlo), "+v"(xhi));
         bf16x8 bfr[NJ];
 #pragma unroll
         for (int jn = 0; jn < NJ; ++jn) bfr[jn] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(blo[jn], bhi[jn], 0, 1, 2, 3, 4, 5, 6, 7));
@@ -261,11 +275,21 @@ __global__ void __launch_bounds__(512) gemm_tn_bf16_v2_kernel(GemmTnArgsB a, int
 #pragma unroll
             for (int jn = 0; jn < NJ; ++jn) acc[i][jn] = mfma_bf16_16x16x32(af, bfr[jn], acc[i][jn]);
         }
+        if constexpr (XP) {
+            if (wn == 0) {
+                const bf16x8 xf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(xlo, xhi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    accx[i] = mfma_bf16_16x16x32(__builtin_bit_cast(bf16x8, __builtin_shufflevector(alo[i], ahi[i], 0, 1, 2, 3, 4, 5, 6, 7)), xf, accx[i]);
+            }
+        }
     };
 
     issue(0); issue(1); issue(2);
     for (int k = 0; k < nst; ++k) {
-        if (NB == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // stage k has landed; k+1, k+2 stay in flight
+        // stage k has landed; k+1, k+2 stay in flight (2 x LDS-DMA instructions per wave and stage)
+        if (NB == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (XP && w == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         __builtin_amdgcn_s_barrier();                     // everyone's part of stage k is in LDS, everyone is done with slot (k+3) % 4
         issue(k + 3);
@@ -286,6 +310,15 @@ __global__ void __launch_bounds__(512) gemm_tn_bf16_v2_kernel(GemmTnArgsB a, int
                 dst[(size_t)m * a.N + n] = acc[i][jn][r];
             }
         }
+    if constexpr (XP) {
+        if (wn == 0 && i16 < a.Nx) {
+            float* dst = nsplit == 1 ? a.Cx : a.partial + (size_t)nsplit * NB * a.M * a.N + (size_t)split * a.M * a.Nx;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[(size_t)(m0 + wm * 128 + i * 16 + g * 4 + r) * a.Nx + i16] = accx[i][r];
+        }
+    }
 }
 
 struct Geo { int tiles_m, tiles_n, nsplit, rows_per_split; };
@@ -323,7 +356,7 @@ size_t gemm_tn_bf16_partial_elems(int R, int M, int N, int NB) {
     size_t e = g.nsplit > 1 ? (size_t)g.nsplit * NB * M * N : 0;
     if (M % V2_MT == 0 && N == 128) {
         const Geo g2 = geometry_v2(R, M);
-        const size_t e2 = g2.nsplit > 1 ? (size_t)g2.nsplit * NB * M * N : 0;
+        const size_t e2 = g2.nsplit > 1 ? (size_t)g2.nsplit * (NB * M * N + (NB == 1 ? M * 16 : 0)) : 0;   // + the optional 16-column product
         if (e2 > e) e = e2;
     }
     return e;
@@ -336,19 +369,25 @@ int launch_gemm_tn_bf16(const GemmTnArgsB& a, hipStream_t s, ReduceJobs* defer) 
     SHM_REQUIRE(a.NB == 1 || (a.Bm2 && a.C2), SHM_EINVAL, "gemm_tn_bf16: second operand missing");
     const bool v2 = v2_ok(a);
     const Geo g = v2 ? geometry_v2(a.R, a.M) : geometry(a.R, a.M, a.N, a.NB);
-    SHM_REQUIRE(g.nsplit == 1 || (a.partial && a.partial_elems >= (size_t)g.nsplit * a.NB * a.M * a.N), SHM_EWORKSPACE,
+    const bool xp = v2 && a.NB == 1 && a.Bx != nullptr;
+    SHM_REQUIRE(!a.Bx || (xp && a.Cx && a.Nx >= 1 && a.Nx <= 16), SHM_EINVAL, "gemm_tn_bf16: the 16-column product needs the H = 128 kernel with NB == 1");
+    SHM_REQUIRE(g.nsplit == 1 || (a.partial && a.partial_elems >= (size_t)g.nsplit * (a.NB * a.M * a.N + (xp ? a.M * a.Nx : 0))), SHM_EWORKSPACE,
                 "gemm_tn_bf16: split-K scratch too small");
     if (v2) {
         const int grid = round_up(g.nsplit, 8) * g.tiles_m;
-        const size_t lds = (size_t)V2_NBUF * (V2_KC * V2_MT * 2 + V2_KC * 128 * a.NB * 2);
+        const size_t lds = (size_t)V2_NBUF * (V2_KC * V2_MT * 2 + V2_KC * 128 * a.NB * 2 + (xp ? V2_KC * 16 * 2 : 0));
         if (a.NB == 2) {
             static bool attr2 = false;
-            if (!attr2) { SHM_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tn_bf16_v2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr2 = true; }
-            hipLaunchKernelGGL(gemm_tn_bf16_v2_kernel<2>, dim3(grid), dim3(512), lds, s, a, g.tiles_m, g.rows_per_split, g.nsplit);
+            if (!attr2) { SHM_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tn_bf16_v2_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr2 = true; }
+            hipLaunchKernelGGL((gemm_tn_bf16_v2_kernel<2, false>), dim3(grid), dim3(512), lds, s, a, g.tiles_m, g.rows_per_split, g.nsplit);
+        } else if (xp) {
+            static bool attrx = false;
+            if (!attrx) { SHM_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tn_bf16_v2_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrx = true; }
+            hipLaunchKernelGGL((gemm_tn_bf16_v2_kernel<1, true>), dim3(grid), dim3(512), lds, s, a, g.tiles_m, g.rows_per_split, g.nsplit);
         } else {
             static bool attr1 = false;
-            if (!attr1) { SHM_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tn_bf16_v2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr1 = true; }
-            hipLaunchKernelGGL(gemm_tn_bf16_v2_kernel<1>, dim3(grid), dim3(512), lds, s, a, g.tiles_m, g.rows_per_split, g.nsplit);
+            if (!attr1) { SHM_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tn_bf16_v2_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr1 = true; }
+            hipLaunchKernelGGL((gemm_tn_bf16_v2_kernel<1, false>), dim3(grid), dim3(512), lds, s, a, g.tiles_m, g.rows_per_split, g.nsplit);
         }
     } else {
         const int tiles = g.tiles_m * g.tiles_n * a.NB;
@@ -358,6 +397,12 @@ int launch_gemm_tn_bf16(const GemmTnArgsB& a, hipStream_t s, ReduceJobs* defer) 
     SHM_LAUNCH_CHECK();
     if (g.nsplit > 1) {
         // partial[split][kb][M*N]: reduce each product with a stride of NB*M*N between splits
+        if (xp) {
+            const float* px = a.partial + (size_t)g.nsplit * a.NB * a.M * a.N;
+            int rc = defer ? reduce_jobs_add(*defer, px, g.nsplit, (size_t)a.M * a.Nx, (size_t)a.M * a.Nx, a.Cx, nullptr)
+                           : launch_reduce_partials(px, g.nsplit, (size_t)a.M * a.Nx, a.Cx, nullptr, s);
+            if (rc) return rc;
+        }
         if (defer) {
             for (int kb = 0; kb < a.NB; ++kb) {
                 int rc = reduce_jobs_add(*defer, a.partial + (size_t)kb * a.M * a.N, g.nsplit, (size_t)a.M * a.N, (size_t)a.NB * a.M * a.N,

@@ -131,7 +131,8 @@ struct LstmFwdArgsB {
     bf16_t* xdrop;          // same layout: the dropout-masked input sequence (written when drop_p > 0), operand of the dW_ih GEMM
     float* h_last;          // [B,H] fp32 or nullptr
     bf16_t* sv_g;           // BPTT records [tile][T][H/16][64] x 16 B {i,f|g,o bf16, c_{t-1}, tanh(c_t) fp32} or nullptr
-    float* sv_c;            // unused (kept for ABI stability of the struct)
+    bf16_t* x_tb;           // fp32-input layer only, optional: tile-blocked bf16 copy of x, [ceil(B/WPT)*T*WPT, 16] (cols >= In not written);
+                            // the dW_ih product of this layer reads it as a third B operand of the dW_hh GEMM
     int B, T, In, in_const, in_f32;
     float drop_p; uint64_t drop_seed; uint32_t drop_stack;
 };
@@ -169,6 +170,7 @@ struct GemmTnArgsB {
     int shift_rows;
     float drop_p; uint64_t drop_seed; uint32_t drop_stack;     // dropout on product 0's B (element index r*N + n)
     float* partial; size_t partial_elems;
+    const void* Bx; float* Cx; int Nx;   // optional third product sharing A (H = 128 kernel, NB == 1): Bx [R, 16] bf16, Cx [M, Nx] = A^T Bx[:, :Nx]
     const void* zeros;             // >= 16 zero bytes (the H = 128 kernel reads them for rows that must contribute nothing); may be NULL
 };
 int launch_gemm_tn_bf16(const GemmTnArgsB& a, hipStream_t s, ReduceJobs* defer = nullptr);

@@ -145,7 +145,10 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int t
         bf16_t* xl = x_lds + buf * XBUF;
         if constexpr (XF32) {
             asm volatile("" : "+v"(X.s0));                 // pin the use (see lstm_bwd_bf16.hip)
-            if (tid < WPT * In) xl[((xk0 / KQX) * 16 + xj0) * RSX + (xk0 % KQX)] = (bf16_t)X.s0;
+            if (tid < WPT * In) {
+                xl[((xk0 / KQX) * 16 + xj0) * RSX + (xk0 % KQX)] = (bf16_t)X.s0;
+                if (a.x_tb) a.x_tb[(((size_t)tile * T + t) * WPT + xj0) * 16 + xk0] = (bf16_t)X.s0;   // operand of the dW_ih GEMM
+            }
         } else {
             asm volatile("" : "+v"(X.v));
             bf16x8 v = X.v;
