@@ -66,6 +66,7 @@ struct shm_vae_plan {
     size_t narrow_scratch;  // block partials of narrow_tn (enc0 dW_ih)
     size_t narrow_scratch2; // block partials of narrow_tn (dW_out): both may be pending in one reduce batch
     size_t pair_sync;       // bf16 path, 2 layers: ticket / progress words of the layer-pipelined launches (zeroed per launch)
+    size_t h0_bf;           // bf16 path: bf16 copy of the decoder input h0 [qt*WPT, H], written by decoder layer 0's forward
     size_t x_tb;            // bf16 path: tile-blocked bf16 copy of x [Rq, 16], written by encoder layer 0's forward, read by its dW_ih product
     size_t misc;            // bf16 path: [64 B sticky error word of the pair launches][256 zero bytes], zeroed by pack_weights
     size_t params_copy;     // flat fp32 copy of the parameters (head / output layer read them unpacked)
@@ -246,6 +247,7 @@ extern "C" int shm_vae_plan_create(const shm_vae_config* cfg, int32_t B, int32_t
     if (bf && L == 2) p->pair_sync = take_bytes(lstm_fwd_pair_sync_bytes(B));
     if (bf) p->misc = take_bytes(64 + 256);
     if (bf) p->x_tb = take_bytes(2 * Rq * 16);
+    if (bf) p->h0_bf = take_bytes(2 * qt * SHM_WPT * H);
     p->params_copy = take((size_t)p->n_params);
     p->h_last = take((size_t)B * H); p->eps = take((size_t)B * Z);
     p->y = take((size_t)B * H); p->xhat = take((size_t)B * H); p->rstd = take(B);
@@ -270,7 +272,9 @@ extern "C" int shm_vae_plan_create(const shm_vae_config* cfg, int32_t B, int32_t
         p->narrow_scratch2 = take(narrow_tn_scratch_elems(H, D));
         p->gemm_partial = take(gp > 0 ? gp : 1);
         if (bf && L == 2) {
-            const size_t eb = gemm_tn_bf16_partial_elems((int)(qt * SHM_WPT * T), 4 * H, H, 1);
+            size_t eb = gemm_tn_bf16_partial_elems((int)(qt * SHM_WPT * T), 4 * H, H, 1);    // encoder layer 0: dW_hh (+ the 16-column dW_ih)
+            const size_t eb2 = gemm_tn_bf16_partial_elems((int)(qt * SHM_WPT * T), 4 * H, H, 2);  // decoder layer 0: dW_ih and dW_hh
+            if (eb2 > eb) eb = eb2;
             p->gemm_partial_b = take(eb > 0 ? eb : 1);
             const size_t ec = gemm_tn_partial_elems(B, 4 * H, H);
             p->gemm_partial_c = take(ec > 0 ? ec : 1);
@@ -379,6 +383,7 @@ extern "C" int shm_vae_forward(shm_vae_plan* p, const float* x, const float* eps
             a.sv_g = save ? at<bf16_t>(ws, st[l].saved) : nullptr;
             a.xdrop = (l > 0 && c.dropout > 0.f) ? at<bf16_t>(ws, st[l].xdrop) : nullptr;
             a.x_tb = (l == 0 && !st[l].in_const) ? at<bf16_t>(ws, p->x_tb) : nullptr;
+            a.h0_bf = st[l].in_const ? at<bf16_t>(ws, p->h0_bf) : nullptr;
             a.B = B; a.T = T; a.In = st[l].In; a.in_const = st[l].in_const ? 1 : 0;
             a.drop_p = l > 0 ? drop : 0.f; a.drop_seed = drop_seed; a.drop_stack = stack;
             return a;
@@ -496,6 +501,7 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
         GemmTnArgsB g;
         memset(&g, 0, sizeof(g));
         g.Bx = Bx; g.Cx = Cx; g.Nx = D;
+        if (dp < 0.f) { g.bcast_T = T; dp = 0.f; }      // dp < 0 marks "Bin holds one row per window"
         g.A = A; g.lda = M; g.ldb = H; g.R = R; g.M = M; g.N = H; g.shift_rows = SHM_WPT;
         if (Bin) { g.NB = 2; g.Bm = Bin; g.C = Cin; g.shift_T = 0; g.Bm2 = Bh; g.C2 = Chh; g.shift_T2 = T; }
         else { g.NB = 1; g.Bm = Bh; g.C = Chh; g.shift_T = T; }
@@ -553,6 +559,12 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
             if (l > 0) {      // with dropout the forward left the masked input in xdrop: no re-hashing in the GEMM
                 const void* xin = drop > 0.f ? at<char>(ws, st[l].xdrop) : at<char>(ws, st[l - 1].h_seq);
                 if ((r = gemm_bf(dps, G, xin, grads + st[l].w_ih, 0.f, stack, at<char>(ws, st[l].h_seq), grads + st[l].w_hh, Rt, defer, part))) return r;
+            } else if (st[l].in_const && H == 128) {
+                // constant-input layer at H = 128: dW_ih = sum_t dpre_t^T bf16(h0) is the first product of the SAME GEMM, its B
+                // operand read as one row per window (the fp32 product over sum_t dpre stays as the fallback below)
+                if ((r = gemm_bf(dps, G, at<char>(ws, p->h0_bf), grads + st[l].w_ih, -1.f, stack, at<char>(ws, st[l].h_seq), grads + st[l].w_hh, Rt,
+                                 defer, part))) return r;
+                goto bias;
             } else {
                 // fp32-input layer at H = 128: dW_ih = dpre^T bf16(x) rides along as a 16-column third product (A is read once)
                 const bool xfuse = !st[l].in_const && H == 128;

@@ -212,6 +212,7 @@ __global__ void __launch_bounds__(512) gemm_tn_bf16_v2_kernel(GemmTnArgsB a, int
             bool ok = r < r_end;
             int rr = ok ? r : r_begin;
             if (sh > 0) { ok = ok && ((rr / a.shift_rows) % sh != 0); rr -= a.shift_rows; }    // h_{t-1}, zero at t = 0
+            else if (!second && a.bcast_T > 0) rr = (rr / (a.shift_rows * a.bcast_T)) * a.shift_rows + rr % a.shift_rows;   // one row per window
             const bf16_t* src = ok ? base + (size_t)rr * a.ldb + b_col[i] : zeros;
             __builtin_amdgcn_global_load_lds((gbl_cvoid*)src, (lds_void*)(buf + A_BYTES + ((NB == 2 ? 2 * w : 0) + (NB == 2 ? i : w)) * 1024), 16, 0, 0);
         }
@@ -323,6 +324,7 @@ __global__ void __launch_bounds__(512) gemm_tn_bf16_v2_kernel(GemmTnArgsB a, int
 
 struct Geo { int tiles_m, tiles_n, nsplit, rows_per_split; };
 bool v2_ok(const GemmTnArgsB& a) {
+    if (a.bcast_T > 0 && !(a.M % V2_MT == 0 && a.N == 128)) return false;
     return a.M % V2_MT == 0 && a.N == 128 && a.lda == a.M && a.ldb == a.N && a.zeros != nullptr && !(a.drop_p > 0.f);
 }
 Geo geometry_v2(int R, int M) {
@@ -368,6 +370,7 @@ int launch_gemm_tn_bf16(const GemmTnArgsB& a, hipStream_t s, ReduceJobs* defer) 
                 "gemm_tn_bf16: M, N, lda, ldb must be multiples of 8 (got %d %d %d %d)", a.M, a.N, a.lda, a.ldb);
     SHM_REQUIRE(a.NB == 1 || (a.Bm2 && a.C2), SHM_EINVAL, "gemm_tn_bf16: second operand missing");
     const bool v2 = v2_ok(a);
+    SHM_REQUIRE(a.bcast_T == 0 || v2, SHM_EINVAL, "gemm_tn_bf16: the per-window operand needs the H = 128 kernel");
     const Geo g = v2 ? geometry_v2(a.R, a.M) : geometry(a.R, a.M, a.N, a.NB);
     const bool xp = v2 && a.NB == 1 && a.Bx != nullptr;
     SHM_REQUIRE(!a.Bx || (xp && a.Cx && a.Nx >= 1 && a.Nx <= 16), SHM_EINVAL, "gemm_tn_bf16: the 16-column product needs the H = 128 kernel with NB == 1");

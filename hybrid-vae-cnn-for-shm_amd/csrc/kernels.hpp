@@ -131,6 +131,7 @@ struct LstmFwdArgsB {
     bf16_t* xdrop;          // same layout: the dropout-masked input sequence (written when drop_p > 0), operand of the dW_ih GEMM
     float* h_last;          // [B,H] fp32 or nullptr
     bf16_t* sv_g;           // BPTT records [tile][T][H/16][64] x 16 B {i,f|g,o bf16, c_{t-1}, tanh(c_t) fp32} or nullptr
+    bf16_t* h0_bf;          // constant-input layer only, optional: bf16 copy of the input [ceil(B/WPT)*WPT, H] (operand of its dW_ih product)
     bf16_t* x_tb;           // fp32-input layer only, optional: tile-blocked bf16 copy of x, [ceil(B/WPT)*T*WPT, 16] (cols >= In not written);
                             // the dW_ih product of this layer reads it as a third B operand of the dW_hh GEMM
     int B, T, In, in_const, in_f32;
@@ -168,6 +169,7 @@ struct GemmTnArgsB {
     int R, M, N;
     int shift_T, shift_T2;         // per product: > 0 -> B row r is taken from row r - shift_rows, zero when (r / shift_rows) % shift_T == 0
     int shift_rows;
+    int bcast_T;                   // > 0: product 0's B is one row per WINDOW ([ceil(B/WPT)*WPT, N]); tile-blocked row r reads row (r / (shift_rows*bcast_T)) * shift_rows + r % shift_rows
     float drop_p; uint64_t drop_seed; uint32_t drop_stack;     // dropout on product 0's B (element index r*N + n)
     float* partial; size_t partial_elems;
     const void* Bx; float* Cx; int Nx;   // optional third product sharing A (H = 128 kernel, NB == 1): Bx [R, 16] bf16, Cx [M, Nx] = A^T Bx[:, :Nx]

@@ -203,6 +203,7 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int t
         const float* h0 = reinterpret_cast<const float*>(a.in);
         const float v = cvalid ? h0[(size_t)cb * H + cu] : 0.f;
         x_lds[my_x_off] = (bf16_t)v;
+        if (a.h0_bf) a.h0_bf[(size_t)cb * H + cu] = (bf16_t)v;     // whole tiles (padding windows: zeros)
         __syncthreads();
 #pragma unroll
         for (int g = 0; g < 4; ++g) xproj[g] = bias4[g];
