@@ -104,7 +104,12 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int t
     const int x_img_off = ((xc8 / KQX) * 16 + xjj) * RSX + (xc8 % KQX);
     const int h_img_off = ((xc8 / KQH) * 16 + xjj) * RSH + (xc8 % KQH);
 
-    struct XSlot { bf16x8 v; float s0; };
+    struct XSlot { unsigned e; float s0; };                // e: one bf16 element (low 16 bits)
+    // bf16 input (layers >= 1): the WPT x H block of a step has exactly NTHR elements, thread <-> element E = tid = jj*H + unit.
+    // Every thread moves (and, with dropout, masks) ITS element; staging 16-byte pieces in wave 0 put the masking of all 4H
+    // inputs (8 hashes + selects per lane) on one wave's path and every other wave waited for it at the barrier.
+    const int ejj = tid / H, eu = tid - ejj * H;
+    const int e_img_off = ((eu / KQX) * 16 + ejj) * RSX + (eu % KQX);
     // XF32 staging: element e < WPT*In of the tile -> (window jj, channel kk); In <= 16 so one element per thread suffices
     const int xe = tid < WPT * In ? tid : 0, xj0 = xe / In, xk0 = xe - xj0 * In;
     const int xb0 = tile * WPT + xj0 < B ? tile * WPT + xj0 : B - 1;
@@ -136,9 +141,9 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int t
             X.s0 = reinterpret_cast<const float*>(a.in)[((size_t)xb0 * T + tc) * In + xk0];
         } else if constexpr (CONSUME) {
             wait_for(tc + 1);
-            X.v = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (uint32_t)(tc * WPT * H + xc * 8) * 2, 0, 16));
+            X.e = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(in_rsrc, (uint32_t)(tc * WPT * H + tid) * 2, 0, 16);
         } else {
-            X.v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(a.in) + ((size_t)tile * T + tc) * WPT * H + (size_t)xc * 8);
+            X.e = reinterpret_cast<const unsigned short*>(a.in)[((size_t)tile * T + tc) * WPT * H + tid];
         }
     };
     auto x_commit = [&](XSlot& X, int t, int buf) {      // t: the step the slot holds
@@ -150,17 +155,16 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int t
                 if (a.x_tb) a.x_tb[(((size_t)tile * T + t) * WPT + xj0) * 16 + xk0] = (bf16_t)X.s0;   // operand of the dW_ih GEMM
             }
         } else {
-            asm volatile("" : "+v"(X.v));
-            bf16x8 v = X.v;
-            if (DROP) {     // element index = (tile-blocked row) * H + unit: identical in dx_gemm and the dW_ih GEMM staging
-                const uint32_t idx = (uint32_t)((((size_t)tile * T + t) * WPT + xjj) * H + xc8);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = drop_hash(a.drop_seed, a.drop_stack, idx + e) >= thr ? (bf16_t)((float)v[e] * dscale) : (bf16_t)0.f;
-                // keep the masked input for the dW_ih GEMM (same tile-blocked layout as the source): hashing it again there
-                // costs more VALU than the GEMM's MFMAs
-                if (tid < NCH) *reinterpret_cast<bf16x8*>(a.xdrop + ((size_t)tile * T + t) * WPT * H + (size_t)xc * 8) = v;
+            asm volatile("" : "+v"(X.e));
+            float f = __uint_as_float(X.e << 16);
+            if (DROP) {     // element index = (tile-blocked row) * H + unit: identical in the backward's dx product and on the host
+                const uint32_t idx = (uint32_t)(((size_t)tile * T + t) * WPT * H + tid);
+                f = drop_hash(a.drop_seed, a.drop_stack, idx) >= thr ? f * dscale : 0.f;
             }
-            if (tid < NCH) *reinterpret_cast<bf16x8*>(xl + x_img_off) = v;
+            const bf16_t v = (bf16_t)f;
+            // keep the masked input for the dW_ih GEMM (same tile-blocked layout as the source)
+            if (DROP) a.xdrop[((size_t)tile * T + t) * WPT * H + tid] = v;
+            xl[e_img_off] = v;
         }
     };
 
@@ -197,6 +201,10 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int t
     };
 
     __syncthreads();
+    // xproj: bias + W_ih x of the step about to run.  Constant input: computed once.  Otherwise it is formed ONE STEP AHEAD,
+    // interleaved with the cell update of the running step: the 4*XK input MFMAs do not depend on h_{t-1}, and issued between
+    // the transcendental VALU work they run on the matrix pipe while the vector pipe computes sigmoid/tanh (both waves of a
+    // SIMD reach this phase together, so without the interleave the matrix pipe idles through every cell update).
     f32x4 xproj[4];
     if constexpr (CONSTIN) {
         // decoder layer 0: the same h0 at every step (temporal_vae.py:68) -> project once, keep in registers
@@ -212,13 +220,17 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int t
         XSlot X;
         x_fetch(X, 0);
         x_commit(X, 0, 0);
+        x_fetch(X, 1);
+        if (T > 1) x_commit(X, 1, 1);
         __syncthreads();
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xproj[g] = bias4[g];
+        mma_x(xproj, x_lds);                               // step 0's input projection
     }
 
     float c = 0.f, h = 0.f;
     u32x4* sv = SAVE ? reinterpret_cast<u32x4*>(a.sv_g) + ((size_t)tile * T * NW + ht) * 64 + lane : nullptr;
 
-    // h_{t} image -> h_seq block (tile, t): 16-byte chunks, fully coalesced; called once the image is complete (after the barrier)
     // vector-memory instructions wave 0 issues per step besides the flag store (h_seq, record, x prefetch, masked x)
     constexpr int OPS = 1 + (SAVE ? 1 : 0) + (CONSTIN ? 0 : 1) + (DROP ? 1 : 0);
     auto h_flush = [&](int t_done, int buf) {
@@ -236,32 +248,40 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int t
             }
         }
     };
-    // X: slot holding x_{t+1}; committed at the end of the step and refilled with x_{t+4}
+    // X: slot holding x_{t+2}; committed at the end of the step (into the buffer of x_t, whose projection step t-1 consumed)
+    // and refilled with x_{t+5}
     auto step = [&](XSlot& X, int t) {
         const int cur = t & 1;
         if (t > 0) h_flush(t - 1, cur);                    // h_{t-1} sits complete in h_lds[cur]
         f32x4 acc[4];
-        if constexpr (CONSTIN) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g] = xproj[g];
-        } else {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g] = bias4[g];
-            mma_x(acc, x_lds + cur * XBUF);
-        }
+        for (int g = 0; g < 4; ++g) acc[g] = xproj[g];
         mma_h(acc, h_lds + cur * HBUF);
 
         float gate[4];
         redeal(acc, gate);
+        if constexpr (!CONSTIN) {                          // x_{t+1} (buffer cur^1) has been in LDS since the last barrier
+#pragma unroll
+            for (int g = 0; g < 4; ++g) xproj[g] = bias4[g];
+            mma_x(xproj, x_lds + (cur ^ 1) * XBUF);
+        }
         const float gi = sigmoid_fast(gate[0]), gf = sigmoid_fast(gate[1]), gg = tanh_fast(gate[2]), go = sigmoid_fast(gate[3]);
         const float c_prev = c;
         c = gf * c + gi * gg;
         const float tc = tanh_fast(c);
         h = go * tc;
+        if constexpr (!CONSTIN) {
+            // one input MFMA per two vector instructions: the matrix pipe works under the transcendental latency
+#pragma unroll
+            for (int i = 0; i < 4 * XK; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x402, 2, 0);
+            }
+        }
         h_lds[(cur ^ 1) * HBUF + my_h_off] = (bf16_t)h;
         if constexpr (!CONSTIN) {
-            if (t + 1 < T) x_commit(X, t + 1, cur ^ 1);
-            x_fetch(X, t + 4);
+            if (t + 2 < T) x_commit(X, t + 2, cur);
+            x_fetch(X, t + 5);
         }
         if constexpr (SAVE) {
             f32x2 a0 = {gi, gf}, a1 = {gg, go};
@@ -276,8 +296,8 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int t
     };
     XSlot X0, X1, X2;
     int t = 0;
-    for (int k = T % 3; k > 0; --k, ++t) { x_fetch(X0, t + 1); step(X0, t); }   // peel: the main loop runs whole triples
-    x_fetch(X0, t + 1); x_fetch(X1, t + 2); x_fetch(X2, t + 3);
+    for (int k = T % 3; k > 0; --k, ++t) { x_fetch(X0, t + 2); step(X0, t); }   // peel: the main loop runs whole triples
+    x_fetch(X0, t + 2); x_fetch(X1, t + 3); x_fetch(X2, t + 4);
     __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0) once: only steady-state loads cross the back-edge
     for (; t + 2 < T; t += 3) {
         step(X0, t);
