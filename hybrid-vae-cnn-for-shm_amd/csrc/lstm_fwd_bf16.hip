@@ -40,6 +40,7 @@ constexpr int WPT = SHM_WPT;     // windows per workgroup
 constexpr int DLY = 4;           // pair launch: a step's h_seq rows are published DLY steps after they were stored
 constexpr unsigned SPIN_MAX = 1u << 21;   // bounded consumer spin (a safety net: ~1 s); on expiry the err word is set
 
+template <int V> struct IntC { static constexpr int value = V; };
 typedef __attribute__((address_space(1))) unsigned gu32;
 #define SHM_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t bytes) {
@@ -260,24 +261,54 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int t
 
         float gate[4];
         redeal(acc, gate);
-        if constexpr (!CONSTIN) {                          // x_{t+1} (buffer cur^1) has been in LDS since the last barrier
+        // Cell update, hand-interleaved with next step's input MFMAs (x_{t+1}, buffer cur^1, in LDS since the last barrier):
+        // two MFMAs between each group of vector instructions, the order pinned with sched_barrier — left to itself the
+        // compiler issues the MFMAs as one block in front of the transcendentals.
+        bf16x8 bx[XK > 0 ? XK : 1];
+        if constexpr (!CONSTIN) {
+            const bf16_t* row = x_lds + (cur ^ 1) * XBUF + (q * 16 + j) * RSX;
+#pragma unroll
+            for (int sx = 0; sx < XK; ++sx) bx[sx] = *reinterpret_cast<const bf16x8*>(row + 8 * sx);
 #pragma unroll
             for (int g = 0; g < 4; ++g) xproj[g] = bias4[g];
-            mma_x(xproj, x_lds + (cur ^ 1) * XBUF);
         }
-        const float gi = sigmoid_fast(gate[0]), gf = sigmoid_fast(gate[1]), gg = tanh_fast(gate[2]), go = sigmoid_fast(gate[3]);
+        auto xm = [&](auto ic) {                           // input MFMAs number 2i, 2i+1 (k-step major, gates 0..3 inner)
+            constexpr int I = decltype(ic)::value;
+            if constexpr (!CONSTIN) {
+#pragma unroll
+                for (int k = 2 * I; k < 2 * I + 2; ++k)
+                    if (k < 4 * XK) xproj[k & 3] = mfma_bf16_16x16x32(wx[k & 3][k >> 2], bx[k >> 2], xproj[k & 3]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        constexpr float L2E = 1.4426950408889634f;
+        __builtin_amdgcn_sched_barrier(0);
+        xm(IntC<0>{});
+        const float e_i = __builtin_amdgcn_exp2f(-L2E * gate[0]), e_f = __builtin_amdgcn_exp2f(-L2E * gate[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        xm(IntC<1>{});
+        const float e_g = __builtin_amdgcn_exp2f(2.0f * L2E * gate[2]), e_o = __builtin_amdgcn_exp2f(-L2E * gate[3]);
+        __builtin_amdgcn_sched_barrier(0);
+        xm(IntC<2>{});
+        const float gi = __builtin_amdgcn_rcpf(1.0f + e_i), gf = __builtin_amdgcn_rcpf(1.0f + e_f);
+        __builtin_amdgcn_sched_barrier(0);
+        xm(IntC<3>{});
+        const float r_g = __builtin_amdgcn_rcpf(1.0f + e_g), go = __builtin_amdgcn_rcpf(1.0f + e_o);
+        __builtin_amdgcn_sched_barrier(0);
+        xm(IntC<4>{});
+        const float gg = 1.0f - 2.0f * r_g;
         const float c_prev = c;
         c = gf * c + gi * gg;
-        const float tc = tanh_fast(c);
+        const float e_c = __builtin_amdgcn_exp2f(2.0f * L2E * c);
+        __builtin_amdgcn_sched_barrier(0);
+        xm(IntC<5>{});
+        const float r_c = __builtin_amdgcn_rcpf(1.0f + e_c);
+        __builtin_amdgcn_sched_barrier(0);
+        xm(IntC<6>{});
+        const float tc = 1.0f - 2.0f * r_c;
         h = go * tc;
-        if constexpr (!CONSTIN) {
-            // one input MFMA per two vector instructions: the matrix pipe works under the transcendental latency
-#pragma unroll
-            for (int i = 0; i < 4 * XK; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x402, 2, 0);
-            }
-        }
+        __builtin_amdgcn_sched_barrier(0);
+        xm(IntC<7>{});
         h_lds[(cur ^ 1) * HBUF + my_h_off] = (bf16_t)h;
         if constexpr (!CONSTIN) {
             if (t + 2 < T) x_commit(X, t + 2, cur);
