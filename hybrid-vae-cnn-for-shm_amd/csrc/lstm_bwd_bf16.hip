@@ -42,6 +42,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint3
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
 template <int V> struct IntC { static constexpr int value = V; };
+__device__ __forceinline__ float redeal1(const f32x4 a) {
+    int v = __float_as_int(a[0]);
+    v = __builtin_amdgcn_update_dpp(v, __float_as_int(a[1]), 0x114, 0xF, 0x2, false);   // row_shr:4  -> lanes 4..7
+    v = __builtin_amdgcn_update_dpp(v, __float_as_int(a[2]), 0x118, 0xF, 0x4, false);   // row_shr:8  -> lanes 8..11
+    v = __builtin_amdgcn_update_dpp(v, __float_as_int(a[3]), 0x11C, 0xF, 0x8, false);   // row_shr:12 -> lanes 12..15
+    return __int_as_float(v);
+}
 
 struct Prefetch {            // operands of one time step of this lane's cell, fetched PD = 3 steps ahead
     u32x4 rec;               // {i,f | g,o (bf16x2 each), c_{t-1}, tanh(c_t)} written by the forward
@@ -111,7 +118,6 @@ __device__ __forceinline__ void lstm_bwd_body(const LstmBwdArgsB& a, const int t
 
     float dc = 0.f, dh_rec = 0.f;
     float tsum[4] = {0.f, 0.f, 0.f, 0.f};
-    float* myscr = scr + ht * 64;
 
     // one time step; P holds this step's operands and is refilled with step t-3 once they are consumed
     auto step = [&](Prefetch& P, int t) {
@@ -177,11 +183,8 @@ __device__ __forceinline__ void lstm_bwd_body(const LstmBwdArgsB& a, const int t
             acc0 = mfma_bf16_16x16x32(whT[s], bv0, acc0);
             acc1 = mfma_bf16_16x16x32(whT[s + 1], bv1, acc1);
         }
-        // accumulator lanes (q, j<4, r) -> cell lanes (same wave: compiler-only barriers)
-        if (j < WPT) *reinterpret_cast<f32x4*>(myscr + (q * 4 + j) * 4) = acc0 + acc1;
-        __builtin_amdgcn_wave_barrier();
-        dh_rec = myscr[(q * 4 + cj) * 4 + cr];
-        __builtin_amdgcn_wave_barrier();
+        // accumulator lanes (q, j<4, r) -> cell lanes (q, jj): register jj>>2 of lane jj&3, by DPP (see lstm_fwd_bf16.hip)
+        dh_rec = redeal1(acc0 + acc1);
     };
 
     __syncthreads();                                       // images zeroed, wo_lds visible
@@ -308,7 +311,6 @@ __device__ __forceinline__ void lstm_bwd_fused_dx_body(const LstmBwdArgsB& a, co
 
     float dc = 0.f, dh_rec = 0.f;
     float tsum[4] = {0.f, 0.f, 0.f, 0.f};
-    float* myscr = scr + ht * 64;
 
     auto step = [&](u32x4& R, int t, auto subc) {
         constexpr int SUB = decltype(subc)::value;         // t & 3 in the main loop, -1 in the peeled steps
@@ -357,10 +359,7 @@ __device__ __forceinline__ void lstm_bwd_fused_dx_body(const LstmBwdArgsB& a, co
             acc1 = mfma_bf16_16x16x32(whT[s + 1], bv1, acc1);
         }
         if constexpr (SUB == 2) chunk_mma(c - 1);
-        if (j < WPT) *reinterpret_cast<f32x4*>(myscr + (q * 4 + j) * 4) = acc0 + acc1;
-        __builtin_amdgcn_wave_barrier();
-        dh_rec = myscr[(q * 4 + cj) * 4 + cr];
-        __builtin_amdgcn_wave_barrier();
+        dh_rec = redeal1(acc0 + acc1);
     };
 
     __syncthreads();                                       // images zeroed
