@@ -73,6 +73,7 @@ struct shm_vae_plan {
     size_t ws_bytes;
     // call-order state
     bool packed, fwd_saved, loss_done, drop_active;
+    int sync_next;          // which of the two pair-launch sync blocks is all-zero and goes to the next pair launch
     uint64_t drop_seed;
     float* recon_ptr;       // where the last forward left recon (caller buffer or workspace)
 };
@@ -244,7 +245,7 @@ extern "C" int shm_vae_plan_create(const shm_vae_config* cfg, int32_t B, int32_t
             }
         }
     }
-    if (bf && L == 2) p->pair_sync = take_bytes(lstm_fwd_pair_sync_bytes(B));
+    if (bf && L == 2) p->pair_sync = take_bytes(2 * lstm_fwd_pair_sync_bytes(B));      // two blocks, used alternately
     if (bf) p->misc = take_bytes(64 + 256);
     if (bf) p->x_tb = take_bytes(2 * Rq * 16);
     if (bf) p->h0_bf = take_bytes(2 * qt * SHM_WPT * H);
@@ -306,15 +307,19 @@ extern "C" int shm_vae_pack_weights(shm_vae_plan* p, const float* params, void* 
     SHM_REQUIRE((reinterpret_cast<uintptr_t>(params) & 15) == 0, SHM_EINVAL, "pack_weights: params must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const int H = p->cfg.hidden_dim, L = p->cfg.num_layers;
-    SHM_HIP_CHECK(hipMemcpyAsync(at<float>(ws, p->params_copy), params, sizeof(float) * p->n_params, hipMemcpyDeviceToDevice, s));
-    if (p->cfg.precision == SHM_PREC_BF16) SHM_HIP_CHECK(hipMemsetAsync(at<char>(ws, p->misc), 0, 64 + 256, s));
-    if (p->cfg.precision == SHM_PREC_BF16) {          // bf16 path: every re-layout in one launch
+    if (p->cfg.precision == SHM_PREC_BF16) {          // bf16 path: every re-layout, the flat copy and the state words in one launch
+        SHM_REQUIRE(p->n_params < ((int64_t)1 << 31), SHM_EINVAL, "pack_weights: parameter count exceeds 2^31");
         PackJobs jobs;
         jobs.n = 0;
         auto add = [&](const float* src, const float* src2, void* dst, int kind, int K) {
             PackJob& j = jobs.job[jobs.n++];
             j.src = src; j.src2 = src2; j.dst = dst; j.kind = kind; j.H = H; j.K = K;
         };
+        add(params, nullptr, at<float>(ws, p->params_copy), 3, (int)p->n_params);
+        add(nullptr, nullptr, at<char>(ws, p->misc), 4, (64 + 256) / 4);                       // sticky error word + zero line
+        if (p->pair_sync)                                                                      // the block the next pair launch uses
+            add(nullptr, nullptr, at<char>(ws, p->pair_sync + (size_t)p->sync_next * lstm_fwd_pair_sync_bytes(p->B)), 4,
+                (int)(lstm_fwd_pair_sync_bytes(p->B) / 4));
         for (int l = 0; l < L; ++l)
             for (int st = 0; st < 2; ++st) {
                 const LayerInst& li = st == 0 ? p->enc[l] : p->dec[l];
@@ -330,6 +335,7 @@ extern "C" int shm_vae_pack_weights(shm_vae_plan* p, const float* params, void* 
         p->packed = true;
         return SHM_OK;
     }
+    SHM_HIP_CHECK(hipMemcpyAsync(at<float>(ws, p->params_copy), params, sizeof(float) * p->n_params, hipMemcpyDeviceToDevice, s));
     for (int l = 0; l < L; ++l) {
         for (int st = 0; st < 2; ++st) {
             const LayerInst& li = st == 0 ? p->enc[l] : p->dec[l];
@@ -390,7 +396,10 @@ extern "C" int shm_vae_forward(shm_vae_plan* p, const float* x, const float* eps
         };
         if (c.precision == SHM_PREC_BF16 && L == 2 && pair_launch_enabled()) {   // both layers in one launch, layer 1 a few steps behind
             LstmFwdPairArgsB pa;
-            pa.l0 = fwd_args(0); pa.l1 = fwd_args(1); pa.sync = at<unsigned>(ws, p->pair_sync); pa.role_lds_off = 0;
+            pa.l0 = fwd_args(0); pa.l1 = fwd_args(1); pa.role_lds_off = 0;
+            pa.sync = at<unsigned>(ws, p->pair_sync + (size_t)p->sync_next * lstm_fwd_pair_sync_bytes(B));
+            pa.sync_other = at<unsigned>(ws, p->pair_sync + (size_t)(p->sync_next ^ 1) * lstm_fwd_pair_sync_bytes(B));
+            p->sync_next ^= 1;
             pa.err = at<unsigned>(ws, p->misc);
             KernelTimer kt(stack == 0 ? "lstm_fwd.enc" : "lstm_fwd.dec", s);
             return launch_lstm_fwd_pair_bf16(H, pa, s);
@@ -589,7 +598,10 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
             bf16_t* dps1 = at<bf16_t>(ws, p->dpre_seq2); float* tsum1 = at<float>(ws, p->dpre_tsum2);
             LstmBwdPairArgsB pa;
             pa.l1 = bwd_args_bf(1, dps1, tsum1); pa.l0 = bwd_args_bf(0, at<bf16_t>(ws, p->dpre_seq), dpre_tsum);
-            pa.sync = at<unsigned>(ws, p->pair_sync); pa.err = at<unsigned>(ws, p->misc); pa.role_lds_off = 0;
+            pa.sync = at<unsigned>(ws, p->pair_sync + (size_t)p->sync_next * lstm_fwd_pair_sync_bytes(B));
+            pa.sync_other = at<unsigned>(ws, p->pair_sync + (size_t)(p->sync_next ^ 1) * lstm_fwd_pair_sync_bytes(B));
+            p->sync_next ^= 1;
+            pa.err = at<unsigned>(ws, p->misc); pa.role_lds_off = 0;
             int r;
             {
                 KernelTimer kt(stack == 0 ? "lstm_bwd.enc" : "lstm_bwd.dec", s);

@@ -139,7 +139,9 @@ struct LstmFwdArgsB {
 };
 int launch_lstm_fwd_bf16(int H, const LstmFwdArgsB& a, hipStream_t s);
 // both layers of a 2-layer stack in one launch, layer 1 running a few steps behind layer 0 on its own workgroups
-struct LstmFwdPairArgsB { LstmFwdArgsB l0, l1; unsigned* sync; unsigned* err; int role_lds_off; };   // sync: zeroed per launch; err: sticky
+// sync: all-zero at launch; sync_other: the block the NEXT pair launch will use, zeroed by this one (the plan alternates two blocks,
+// which replaces a memset in front of every launch); err: sticky
+struct LstmFwdPairArgsB { LstmFwdArgsB l0, l1; unsigned* sync; unsigned* sync_other; unsigned* err; int role_lds_off; };
 size_t lstm_fwd_pair_sync_bytes(int B);
 int launch_lstm_fwd_pair_bf16(int H, const LstmFwdPairArgsB& p, hipStream_t s);
 
@@ -157,7 +159,7 @@ int launch_lstm_bwd_bf16(int H, const LstmBwdArgsB& a, hipStream_t s);      // r
 int launch_dx_gemm_bf16(int H, const LstmBwdArgsB& a, hipStream_t s);       // time-parallel part: dx_seq = dpre_seq . W_ih
 // both layers of a 2-layer stack in one launch: l1 = top layer (its dpre_seq is handed to l0 inside the launch), l0 forms
 // dx = dpre^1 W_ih^1 itself; the two dpre_seq / dpre_tsum buffers must be distinct
-struct LstmBwdPairArgsB { LstmBwdArgsB l1, l0; unsigned* sync; unsigned* err; int role_lds_off; };
+struct LstmBwdPairArgsB { LstmBwdArgsB l1, l0; unsigned* sync; unsigned* sync_other; unsigned* err; int role_lds_off; };
 int launch_lstm_bwd_pair_bf16(int H, const LstmBwdPairArgsB& p, hipStream_t s);
 
 struct GemmTnArgsB {
@@ -179,8 +181,8 @@ int launch_gemm_tn_bf16(const GemmTnArgsB& a, hipStream_t s, ReduceJobs* defer =
 size_t gemm_tn_bf16_partial_elems(int R, int M, int N, int NB);
 
 // all bf16 re-layouts + bias sums of one parameter update in a single launch
-struct PackJob { const float* src; const float* src2; void* dst; int kind, H, K; };   // kind 0: fwd operand (K = in width), 1: bwd operand (K = M), 2: bias sum
-struct PackJobs { PackJob job[20]; int n; };
+struct PackJob { const float* src; const float* src2; void* dst; int kind, H, K; };   // kind 0: fwd operand (K = in width), 1: bwd operand (K = M), 2: bias sum, 3: copy K floats, 4: zero K dwords
+struct PackJobs { PackJob job[24]; int n; };
 int launch_pack_all(const PackJobs& jobs, hipStream_t s);
 int launch_pack_fwd_bf16(const float* W, int H, int K, bf16_t* dst, hipStream_t s);
 int launch_pack_bwd_bf16(const float* W, int H, int M, bf16_t* dst, hipStream_t s);

@@ -387,7 +387,7 @@ __device__ __forceinline__ void lstm_bwd_fused_dx_body(const LstmBwdArgsB& a, co
     }
 }
 
-// sync: [0] ticket, flag of tile i at sync[16 * (1 + i)], zeroed by the launcher; err: sticky word outside that block
+// sync: [0] ticket, flag of tile i at sync[16 * (1 + i)], all zero at launch (see lstm_fwd_bf16.hip); err: sticky word outside
 template <int H, int DHTOP, bool DROP>
 __global__ void __launch_bounds__(4 * H) lstm_bwd_pair_bf16_kernel(LstmBwdPairArgsB p) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem_b[];
@@ -398,6 +398,10 @@ __global__ void __launch_bounds__(4 * H) lstm_bwd_pair_bf16_kernel(LstmBwdPairAr
     __syncthreads();
     const int role = *role_lds;
     __syncthreads();
+    if (threadIdx.x == 0 && role < tiles) {               // nobody touches the other block in this launch
+        p.sync_other[16 * (1 + role)] = 0u;
+        if (role == 0) p.sync_other[0] = 0u;
+    }
     if (role < tiles) lstm_bwd_body<H, DHTOP, true>(p.l1, role, sync + 16 * (1 + role));
     else lstm_bwd_fused_dx_body<H, DROP>(p.l0, p.l1, role - tiles, sync + 16 * (1 + role - tiles), (gu32*)p.err);
 }
@@ -502,7 +506,7 @@ int launch_pair(const LstmBwdPairArgsB& p0, hipStream_t s) {
     const LstmBwdArgsB &t = p.l1, &b = p.l0;
     SHM_REQUIRE(t.sv_g && b.sv_g && t.dpre_seq && b.dpre_seq && t.dpre_seq != b.dpre_seq, SHM_ESTATE, "lstm_bwd_pair: saved state / two dpre buffers needed");
     SHM_REQUIRE(t.WhT && b.WhT && t.WxT && t.In == H, SHM_EINVAL, "lstm_bwd_pair: packed weights missing");
-    SHM_REQUIRE(t.B == b.B && t.T == b.T && p.sync && p.err, SHM_EINVAL, "lstm_bwd_pair: shape mismatch or no sync block");
+    SHM_REQUIRE(t.B == b.B && t.T == b.T && p.sync && p.sync_other && p.sync != p.sync_other && p.err, SHM_EINVAL, "lstm_bwd_pair: shape mismatch or no sync block");
     SHM_REQUIRE(!t.dy || (t.Wout && t.Dy > 0 && t.Dy <= 64), SHM_EINVAL, "lstm_bwd_pair: bad output-layer gradient");
     SHM_REQUIRE((int64_t)t.T * WPT * 4 * H * 2 < ((int64_t)1 << 31), SHM_EINVAL, "lstm_bwd_pair: T too long for 32-bit buffer offsets");
     const int tiles = ceil_div(t.B, WPT);
@@ -511,7 +515,6 @@ int launch_pair(const LstmBwdPairArgsB& p0, hipStream_t s) {
     const size_t lds_bot = 3 * img + sizeof(float) * ((H / 16) * 64 + 2 * 16 * H);
     const size_t lds = ((lds_top > lds_bot ? lds_top : lds_bot) + 15) & ~(size_t)15;
     p.role_lds_off = (int)lds;
-    SHM_HIP_CHECK(hipMemsetAsync(p.sync, 0, lstm_fwd_pair_sync_bytes(t.B), s));
     const bool drop = t.drop_p > 0.f;
     void (*kern)(LstmBwdPairArgsB);
     if (t.dy) kern = t.Dy == 4 ? (drop ? lstm_bwd_pair_bf16_kernel<H, 2, true> : lstm_bwd_pair_bf16_kernel<H, 2, false>)

@@ -348,8 +348,9 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_bf16_kernel(LstmFwdArgsB a) {
     lstm_fwd_body<H, XK, XF32, DROP, CONSTIN, SAVE, false, false>(a, blockIdx.x, nullptr, nullptr, nullptr);
 }
 
-// Two layers, one launch.  sync: [0] ticket, flag of tile i at sync[16 * (1 + i)] (a 64-byte line each), zeroed by the
-// launcher's memset before every launch; err: a sticky word outside that block.
+// Two layers, one launch.  sync: [0] ticket, flag of tile i at sync[16 * (1 + i)] (a 64-byte line each), all zero at launch:
+// the previous pair launch zeroed it (the plan alternates two blocks; shm_vae_pack_weights zeroes the first); err: a sticky
+// word outside those blocks.
 template <int H, bool XF32_0, bool DROP, bool SAVE>
 __global__ void __launch_bounds__(4 * H) lstm_fwd_pair_bf16_kernel(LstmFwdPairArgsB p) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem_b[];
@@ -361,6 +362,10 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_pair_bf16_kernel(LstmFwdPairAr
     __syncthreads();
     const int role = *role_lds;
     __syncthreads();
+    if (threadIdx.x == 0 && role < tiles) {               // nobody touches the other block in this launch
+        p.sync_other[16 * (1 + role)] = 0u;
+        if (role == 0) p.sync_other[0] = 0u;
+    }
     if (role < tiles) {
         if constexpr (XF32_0) lstm_fwd_body<H, 1, true, false, false, SAVE, false, true>(p.l0, role, nullptr, sync + 16 * (1 + role), (gu32*)p.err);
         else lstm_fwd_body<H, H / 32, false, false, true, SAVE, false, true>(p.l0, role, nullptr, sync + 16 * (1 + role), (gu32*)p.err);
@@ -406,7 +411,7 @@ template <int H>
 int launch_pair_h(const LstmFwdPairArgsB& p0, hipStream_t s) {
     LstmFwdPairArgsB p = p0;
     const LstmFwdArgsB &a = p.l0, &b = p.l1;
-    SHM_REQUIRE(a.h_seq && b.h_seq && p.sync && p.err, SHM_EINVAL, "lstm_fwd_pair: h_seq or sync is NULL");
+    SHM_REQUIRE(a.h_seq && b.h_seq && p.sync && p.sync_other && p.sync != p.sync_other && p.err, SHM_EINVAL, "lstm_fwd_pair: h_seq or sync is NULL");
     SHM_REQUIRE(b.in == (const void*)a.h_seq && !b.in_f32 && !b.in_const && b.In == H, SHM_EINVAL, "lstm_fwd_pair: layer 1 must read layer 0's h_seq");
     SHM_REQUIRE(a.B == b.B && a.T == b.T, SHM_EINVAL, "lstm_fwd_pair: shape mismatch");
     SHM_REQUIRE((a.sv_g != nullptr) == (b.sv_g != nullptr), SHM_EINVAL, "lstm_fwd_pair: both layers save or neither");
@@ -419,7 +424,6 @@ int launch_pair_h(const LstmFwdPairArgsB& p0, hipStream_t s) {
     const int tiles = ceil_div(a.B, WPT);
     const size_t lds = sizeof(bf16_t) * 2 * 4 * 16 * (lds_row_stride(H / 4) + lds_row_stride(H / 4)) + sizeof(float) * (H / 16) * 256;
     p.role_lds_off = (int)lds;
-    SHM_HIP_CHECK(hipMemsetAsync(p.sync, 0, lstm_fwd_pair_sync_bytes(a.B), s));
     void (*kern)(LstmFwdPairArgsB);
     if (xf32) kern = drop ? (save ? lstm_fwd_pair_bf16_kernel<H, true, true, true> : lstm_fwd_pair_bf16_kernel<H, true, true, false>)
                           : (save ? lstm_fwd_pair_bf16_kernel<H, true, false, true> : lstm_fwd_pair_bf16_kernel<H, true, false, false>);

@@ -604,9 +604,15 @@ __global__ void __launch_bounds__(256) pack_all_kernel(PackJobs jobs) {
             const int k = (lane >> 4) * H + 8 * s + e, m = mt * 16 + (lane & 15);
             dst[i] = (bf16_t)(m < M ? jb.src[(size_t)k * M + m] : 0.f);
         }
-    } else {                       // bias sum b_ih + b_hh
+    } else if (jb.kind == 2) {     // bias sum b_ih + b_hh
         float* dst = reinterpret_cast<float*>(jb.dst);
         for (size_t i = i0; i < (size_t)4 * H; i += stride) dst[i] = jb.src[i] + jb.src2[i];
+    } else if (jb.kind == 3) {     // plain copy of K floats (the flat parameter copy)
+        float* dst = reinterpret_cast<float*>(jb.dst);
+        for (size_t i = i0; i < (size_t)jb.K; i += stride) dst[i] = jb.src[i];
+    } else {                       // kind 4: zero K dwords (sticky error word, zero line, sync block)
+        unsigned* dst = reinterpret_cast<unsigned*>(jb.dst);
+        for (size_t i = i0; i < (size_t)jb.K; i += stride) dst[i] = 0u;
     }
 }
 __global__ void __launch_bounds__(256) bias_sum_kernel(const float* __restrict__ a, const float* __restrict__ b, int n, float* __restrict__ dst) {
