@@ -68,9 +68,11 @@ def pmc_traffic(label, precision):
     if precision != "bf16" or not PMC_SUMMARY.exists():
         return None
     kind, _, inst = label.partition(".")
-    want = {"lstm_fwd": {"enc0": "lstm_fwd_bf16_kernel<128, 1, true", "dec0": "lstm_fwd_bf16_kernel<128, 4, false, false, true",
+    want = {"lstm_fwd": {"enc": "lstm_fwd_pair_bf16_kernel<128, true", "dec": "lstm_fwd_pair_bf16_kernel<128, false",
+                         "enc0": "lstm_fwd_bf16_kernel<128, 1, true", "dec0": "lstm_fwd_bf16_kernel<128, 4, false, false, true",
                          "enc1": "lstm_fwd_bf16_kernel<128, 4, false, true, false", "dec1": "lstm_fwd_bf16_kernel<128, 4, false, true, false"},
-            "lstm_bwd": {"enc0": "lstm_bwd_bf16_kernel<128, 1>", "dec0": "lstm_bwd_bf16_kernel<128, 1>",
+            "lstm_bwd": {"enc": "lstm_bwd_pair_bf16_kernel<128, 0", "dec": "lstm_bwd_pair_bf16_kernel<128, 2",
+                         "enc0": "lstm_bwd_bf16_kernel<128, 1>", "dec0": "lstm_bwd_bf16_kernel<128, 1>",
                          "enc1": "lstm_bwd_bf16_kernel<128, 0>", "dec1": "lstm_bwd_bf16_kernel<128, 2>"}}.get(kind, {}).get(inst)
     if not want:
         return None
