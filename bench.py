@@ -194,6 +194,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     stats = trainer.stats.cpu().tolist()
+    trainer.engine.check_status()          # raises if an in-launch layer hand-off ever timed out (results would be invalid)
 
     # per-kernel durations with HIP events on the launch stream (outside the timed region)
     roof = None
@@ -213,6 +214,7 @@ def main():
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 5), "traffic": pmc_traffic(dom, args.precision), "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
                 "avg_launch_ms": round(per[dom], 4),
+                "hbm_achieved_GBps": (round(pmc_traffic(dom, args.precision) / (per[dom] * 1e-3) / 1e9, 1) if pmc_traffic(dom, args.precision) else None),
                 "alg_flops_per_launch": fl, "kernels_ms": {k: round(v, 4) for k, v in sorted(per.items())}}
     barrier()
 
