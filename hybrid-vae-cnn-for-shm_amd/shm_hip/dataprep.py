@@ -81,3 +81,27 @@ def windows_by_index(files, window_indices, split: str, win_len: int, num_featur
     if not out:
         return np.zeros((0, win_len, num_features), dtype=np.float32)
     return np.concatenate(out, axis=0)
+
+
+# ---- openLAB variant (20250506_openLAB_tests/Codes/04_train_vae.py:106-127): NaN-aware statistics over (N, T), std floor 1e-12 -> 1,
+# z-scores clipped to +-clip_z BEFORE the NaN/inf -> 0 replacement, optional channel selection.
+def fit_mean_std_openlab(X: np.ndarray):
+    mu = np.nanmean(X, axis=(0, 1)).astype(np.float32)
+    sd = np.nanstd(X, axis=(0, 1)).astype(np.float32)
+    sd = np.where(sd < 1e-12, 1.0, sd).astype(np.float32)
+    return mu, sd
+
+
+def standardize_openlab(X: np.ndarray, mu: np.ndarray, sd: np.ndarray, clip_z: float) -> np.ndarray:
+    Xn = (X - mu[None, None, :]) / sd[None, None, :]
+    Xn = np.clip(Xn, -float(clip_z), float(clip_z))
+    return np.nan_to_num(Xn, nan=0.0, posinf=0.0, neginf=0.0).astype(np.float32)
+
+
+def select_channels(X: np.ndarray, idx):
+    idx = list(idx)
+    if X.ndim != 3:
+        raise ValueError(f"Expected 3D tensor (N,T,C); got shape {X.shape}.")
+    if max(idx) >= X.shape[2]:
+        raise ValueError(f"CHANNELS_IDX out of range for C={X.shape[2]}.")
+    return X[:, :, idx], idx

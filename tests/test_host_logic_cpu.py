@@ -1,5 +1,6 @@
 """CPU tests of the host-side rows: KL schedules (a7) and data preparation (a9) against the reference goldens."""
 import numpy as np
+import pytest
 
 from conftest import load_golden
 from shm_hip import dataprep, schedules
@@ -41,3 +42,21 @@ def test_mean_std_rules():
     assert np.isfinite(Z).all()
     bad = W.copy(); bad[0, 0, 0] = np.nan; bad[0, 1, 1] = np.inf
     assert np.isfinite(dataprep.normalize_windows(bad, mean, std)).all()
+
+
+def test_openlab_standardize_semantics():
+    """openLAB data prep (Codes/04_train_vae.py:106-127).  The script cannot be imported without its config/plot side effects, so
+    this is pinned by hand-computed values (parity unpinned by a reference artefact): NaN-aware stats, std floor, clip, NaN -> 0."""
+    from shm_hip import dataprep
+    X = np.array([[[1.0, 5.0, np.nan], [3.0, 5.0, 2.0]], [[5.0, 5.0, 4.0], [7.0, 5.0, 100.0]]], dtype=np.float32)   # [N=2,T=2,C=3]
+    mu, sd = dataprep.fit_mean_std_openlab(X)
+    assert np.allclose(mu, [4.0, 5.0, np.nanmean([2.0, 4.0, 100.0])])
+    assert sd[1] == 1.0 and np.isclose(sd[0], np.std([1, 3, 5, 7]))                 # constant channel: std < 1e-12 -> 1
+    Z = dataprep.standardize_openlab(X, mu, sd, clip_z=1.0)
+    assert Z.dtype == np.float32 and Z[0, 0, 2] == 0.0                              # NaN -> 0
+    assert Z.max() <= 1.0 and Z.min() >= -1.0 and Z[1, 1, 2] == 1.0                 # clipped
+    assert np.allclose(Z[:, :, 1], 0.0)
+    Xs, idx = dataprep.select_channels(X, [2, 0])
+    assert Xs.shape == (2, 2, 2) and idx == [2, 0] and Xs[1, 1, 0] == 100.0
+    with pytest.raises(ValueError):
+        dataprep.select_channels(X, [3])
