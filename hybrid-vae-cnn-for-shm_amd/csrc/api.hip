@@ -441,7 +441,8 @@ extern "C" int shm_vae_forward(shm_vae_plan* p, const float* x, const float* eps
     {
         KernelTimer kt("out_fwd", s);
         if ((rc = launch_out_fwd(B, T, D, H, at<char>(ws, p->dec[L - 1].h_seq), c.precision == SHM_PREC_BF16, prm + p->out_w, prm + p->out_b, x, rec,
-                                 at<float>(ws, p->score), s))) return rc;
+                                 at<float>(ws, p->score), s,
+                                 (c.precision == SHM_PREC_BF16 && p->training) ? at<float>(ws, p->d_recon) : nullptr))) return rc;
     }
     if (score) SHM_HIP_CHECK(hipMemcpyAsync(score, at<float>(ws, p->score), sizeof(float) * B, hipMemcpyDeviceToDevice, s));
     p->recon_ptr = rec;
@@ -475,7 +476,7 @@ extern "C" int shm_vae_loss(shm_vae_plan* p, const float* x, float kl_w, float* 
     SHM_REQUIRE(x && losses, SHM_EINVAL, "loss: x or losses is NULL");
     const shm_vae_config& c = p->cfg;
     if ((rc = launch_vae_loss(p->B, p->T, c.input_dim, c.latent_dim, x, p->recon_ptr, at<float>(ws, p->mu), at<float>(ws, p->lv),
-                              kl_w, at<float>(ws, p->d_recon), at<float>(ws, p->d_mu), at<float>(ws, p->d_lv),
+                              kl_w, c.precision == SHM_PREC_BF16 ? nullptr : at<float>(ws, p->d_recon), at<float>(ws, p->d_mu), at<float>(ws, p->d_lv),
                               at<float>(ws, p->score), losses, (hipStream_t)stream))) return rc;
     p->loss_done = true;
     return SHM_OK;

@@ -267,14 +267,19 @@ __global__ void __launch_bounds__(256) out_fwd_kernel(int T, int D, int H, const
 // contiguous block; a wave takes 16 rows (= 4 steps x 4 windows) per MFMA chain, A = h rows straight from HBM (16-byte
 // fragments), B = W_out^T fragments in registers.  Accumulator row 4q+r <-> (step t0+q, window r), column j = channel, so
 // each lane adds the squared error of ONE window (r) and the per-window score needs no atomics.
+// 8 waves per tile, 4 groups (64 rows) requested per wave and pass: a tile at T = 256 is two memory round trips
+// (4 waves walking 16 groups each with dependent loads took 57 us; the kernel is pure latency).  d_recon (optional) is the
+// gradient of the mean-squared error, 2 (recon - x) / (B T D), written here so that the loss kernel has no pass over [B,T,D].
+constexpr int OUT_WAVES = 8;
 template <int H>
-__global__ void __launch_bounds__(256) out_fwd_mfma_kernel(int B, int T, int D, const bf16_t* __restrict__ h_seq,
+__global__ void __launch_bounds__(64 * OUT_WAVES) out_fwd_mfma_kernel(int B, int T, int D, const bf16_t* __restrict__ h_seq,
                                                            const float* __restrict__ Wout, const float* __restrict__ bout,
                                                            const float* __restrict__ x, float* __restrict__ recon,
-                                                           float* __restrict__ score) {
+                                                           float* __restrict__ score, float* __restrict__ d_recon) {
     static_assert(SHM_WPT == 4, "row <-> (step, window) mapping below assumes 4-window tiles");
     constexpr int KS = H / 32;
-    __shared__ float red[4][4][64];
+    __shared__ float red[OUT_WAVES][4][64];
+    const float dsc = 2.0f / ((float)B * (float)T * (float)D);
     const int tile = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
     bf16x8 wf[KS];                      // B operand: lane (q,j) holds W_out[j][8q + 32s .. +7] (zero for j >= D)
 #pragma unroll
@@ -289,7 +294,7 @@ __global__ void __launch_bounds__(256) out_fwd_mfma_kernel(int B, int T, int D, 
     // GB groups per wave and pass: all their fragment loads (GB x KS x 16 B per lane) are in flight before the first MFMA
     constexpr int GB = 4;
     const bf16x8 zero8 = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
-    for (int g0 = w * GB; g0 < n_groups; g0 += 4 * GB) {
+    for (int g0 = w * GB; g0 < n_groups; g0 += OUT_WAVES * GB) {
         bf16x8 af[GB][KS];
 #pragma unroll
         for (int gi = 0; gi < GB; ++gi) {
@@ -315,6 +320,7 @@ __global__ void __launch_bounds__(256) out_fwd_mfma_kernel(int B, int T, int D, 
                         const float rc = acc[r] + bias;
                         if (recon) recon[o] = rc;
                         const float e = x[o] - rc;
+                        if (d_recon) d_recon[o] = -e * dsc;
                         sq[r] = fmaf(e, e, sq[r]);
                     }
                 }
@@ -327,7 +333,7 @@ __global__ void __launch_bounds__(256) out_fwd_mfma_kernel(int B, int T, int D, 
     if (threadIdx.x < 4 && score) {                                   // fixed-order sum: deterministic
         const int r = threadIdx.x, b = tile * 4 + r;
         float tot = 0.f;
-        for (int ww = 0; ww < 4; ++ww)
+        for (int ww = 0; ww < OUT_WAVES; ++ww)
             for (int l = 0; l < 64; ++l) tot += red[ww][r][l];
         if (b < B) score[b] = tot / (float)(T * D);
     }
@@ -341,8 +347,9 @@ __global__ void __launch_bounds__(256) vae_loss_kernel(int B, int T, int D, int 
                                                        float* __restrict__ d_lv, float* __restrict__ losses) {
     const size_t n = (size_t)B * T * D;
     const float sc = 2.0f / (float)n;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
-        d_recon[i] = (recon[i] - x[i]) * sc;
+    if (d_recon)                                          // bf16 path: already written by out_fwd
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+            d_recon[i] = (recon[i] - x[i]) * sc;
     if (blockIdx.x == 0) {
         __shared__ float red[2][4];
         const int nz = B * Z;
@@ -645,14 +652,15 @@ int launch_head_grads(int B, int H, int Z, int layer_norm, const HeadBufs& hb, f
     return SHM_OK;
 }
 int launch_out_fwd(int B, int T, int D, int H, const void* h_seq, int h_bf16, const float* Wout, const float* bout, const float* x,
-                   float* recon, float* score, hipStream_t s) {
+                   float* recon, float* score, hipStream_t s, float* d_recon) {
+    SHM_REQUIRE(!d_recon || h_bf16, SHM_EINVAL, "out: d_recon is written by the bf16 kernel only");
     SHM_REQUIRE(D <= DMAX && H <= HMAX, SHM_EINVAL, "out: D=%d (<=%d) H=%d unsupported", D, DMAX, H);
     if (h_bf16) {
         const int tiles = ceil_div(B, SHM_WPT);
         const bf16_t* hs = (const bf16_t*)h_seq;
-        if (H == 128) hipLaunchKernelGGL(out_fwd_mfma_kernel<128>, dim3(tiles), dim3(256), 0, s, B, T, D, hs, Wout, bout, x, recon, score);
-        else if (H == 64) hipLaunchKernelGGL(out_fwd_mfma_kernel<64>, dim3(tiles), dim3(256), 0, s, B, T, D, hs, Wout, bout, x, recon, score);
-        else hipLaunchKernelGGL(out_fwd_mfma_kernel<32>, dim3(tiles), dim3(256), 0, s, B, T, D, hs, Wout, bout, x, recon, score);
+        if (H == 128) hipLaunchKernelGGL(out_fwd_mfma_kernel<128>, dim3(tiles), dim3(64 * OUT_WAVES), 0, s, B, T, D, hs, Wout, bout, x, recon, score, d_recon);
+        else if (H == 64) hipLaunchKernelGGL(out_fwd_mfma_kernel<64>, dim3(tiles), dim3(64 * OUT_WAVES), 0, s, B, T, D, hs, Wout, bout, x, recon, score, d_recon);
+        else hipLaunchKernelGGL(out_fwd_mfma_kernel<32>, dim3(tiles), dim3(64 * OUT_WAVES), 0, s, B, T, D, hs, Wout, bout, x, recon, score, d_recon);
     }
     else
         hipLaunchKernelGGL((out_fwd_kernel<float, false>), dim3(B), dim3(256), 0, s, T, D, H, (const float*)h_seq, Wout, bout, x, recon, score);
@@ -662,7 +670,7 @@ int launch_out_fwd(int B, int T, int D, int H, const void* h_seq, int h_bf16, co
 int launch_vae_loss(int B, int T, int D, int Z, const float* x, const float* recon, const float* mu, const float* lv,
                     float kl_w, float* d_recon, float* d_mu, float* d_lv, float* score, float* losses, hipStream_t s) {
     const size_t n = (size_t)B * T * D;
-    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    const int blocks = d_recon ? (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048) : 1;
     hipLaunchKernelGGL(vae_loss_kernel, dim3(blocks), dim3(256), 0, s, B, T, D, Z, x, recon, mu, lv, score, kl_w, d_recon, d_mu, d_lv, losses);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
