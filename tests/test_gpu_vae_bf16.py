@@ -145,7 +145,8 @@ def test_bf16_layer_pipelined_launch_is_bit_identical(train_mode):
     from Scripts.Models.temporal_vae import TemporalVAE
     from shm_hip._capi import lib
     from shm_hip.trainer import VAETrainer
-    for (B, T, H) in ((512, 256, 128), (510, 100, 128), (37, 50, 64), (9, 31, 32)):
+    # incl. degenerate lengths: T < the hand-off delay (4), T < one 4-step dx chunk, a single window
+    for (B, T, H) in ((512, 256, 128), (510, 100, 128), (37, 50, 64), (9, 31, 32), (1, 1, 128), (3, 2, 128), (5, 3, 64), (2, 5, 32), (4, 7, 128)):
         torch.manual_seed(11)
         m = TemporalVAE(4, 16, H, 2, 0.3, precision="bf16").cuda()
         gen = torch.Generator().manual_seed(B)
@@ -174,3 +175,30 @@ def test_bf16_layer_pipelined_launch_is_bit_identical(train_mode):
             else:
                 for a, b in zip(ref, out):
                     assert torch.equal(a, b), (B, T, H, on, float((a - b).abs().max()))
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 128), (3, 2, 128), (5, 3, 64), (2, 5, 32), (4, 7, 128), (6, 13, 64)])
+def test_bf16_matches_fp32_path_at_degenerate_shapes(shape):
+    """The fp32 path is pinned to the reference at the golden shapes; here it is the checker for sequence lengths around the
+    kernels' pipeline depths (hand-off delay 4, 4-step dx chunks, prefetch depth 3/4) and for single windows."""
+    from Scripts.Models.temporal_vae import TemporalVAE
+    from shm_hip.trainer import VAETrainer
+    B, T, H = shape
+    gen = torch.Generator().manual_seed(1000 + B * 31 + T)
+    x = torch.randn(B, T, 4, generator=gen).cuda()
+    eps = torch.randn(B, 8, generator=gen).cuda()
+    out = {}
+    for prec in ("fp32", "bf16"):
+        torch.manual_seed(5)
+        m = TemporalVAE(4, 8, H, 2, 0.0, precision=prec).cuda().train()
+        tr = VAETrainer(m, lr=1e-3, weight_decay=0.0, max_norm=2.0)
+        stats = tr.step(x, 0.25, eps=eps).cpu().numpy()
+        tr.engine.check_status()
+        with torch.no_grad(), inject_eps([eps.cpu()]):
+            recon, mu, lv = m.eval()(x)
+        out[prec] = (stats, tr.grads.cpu().numpy().astype(np.float64), recon.cpu().numpy())
+    s32, g32, r32 = out["fp32"]
+    s16, g16, r16 = out["bf16"]
+    assert abs(s16[0] - s32[0]) < 2e-3 * max(1.0, abs(s32[0])), (s16, s32)
+    assert np.linalg.norm(g16 - g32) < 3e-2 * max(np.linalg.norm(g32), 1e-9), np.linalg.norm(g16 - g32) / np.linalg.norm(g32)
+    assert np.abs(r16 - r32).max() < 5e-3
