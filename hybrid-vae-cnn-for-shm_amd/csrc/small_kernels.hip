@@ -451,6 +451,26 @@ __global__ void __launch_bounds__(256) reduce_batch_kernel(ReduceJobs jobs) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ on-device windowing
+// out[n][t][d] = nan_to_num((series[starts[n] + t][d] - mean[d]) / std[d]) — make_windows + normalize of the reference's
+// data prep (4DOF/Scripts/03_train_vae.py:98-117) without the T-fold host copy: the raw series stays on the device and every
+// window row is gathered from it (HBM-bound; the series is re-read T times out of L2/MALL, the output is written once).
+__global__ void __launch_bounds__(256) window_gather_kernel(const float* __restrict__ series, long long n_rows, int D,
+                                                            const int* __restrict__ starts, int N, int T,
+                                                            const float* __restrict__ mean, const float* __restrict__ stdv,
+                                                            float* __restrict__ out) {
+    const size_t per = (size_t)T * D, total = (size_t)N * per;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t n = i / per, r = i - n * per;
+        const int d = (int)(r % D);
+        long long row = (long long)starts[n] + (long long)(r / D);
+        row = row < 0 ? 0 : (row >= n_rows ? n_rows - 1 : row);          // the host wrapper validates; never read out of bounds
+        float v = series[(size_t)row * D + d];
+        if (mean) v = (v - mean[d]) / stdv[d];
+        out[i] = (v != v || v == INFINITY || v == -INFINITY) ? 0.f : v;  // nan_to_num(nan=0, posinf=0, neginf=0)
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ narrow TN product
 // out[n][m] = sum_r Bn[r][n] * A[r][m]  with n < N <= 16 (channel count): dW_out = d_recon^T h_top, dW_ih(enc0) = dpre^T x.
 // A is streamed once (HBM-bound, 2 columns per thread); Bn is a broadcast load.  Block partials -> reduce_partials.
@@ -683,6 +703,15 @@ int launch_reduce_partials(const float* partial, int nparts, size_t n, float* ou
 }
 int launch_reduce_partials_strided(const float* partial, int nparts, size_t n, size_t stride, float* out0, hipStream_t s) {
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, partial, nparts, n, stride, out0, (float*)nullptr, (float*)nullptr);
+    SHM_LAUNCH_CHECK();
+    return SHM_OK;
+}
+int launch_window_gather(const float* series, long long n_rows, int D, const int* starts, int N, int T, const float* mean, const float* stdv,
+                         float* out, hipStream_t s) {
+    if (N == 0) return SHM_OK;
+    const size_t total = (size_t)N * T * D;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(window_gather_kernel, dim3(blocks), dim3(256), 0, s, series, n_rows, D, starts, N, T, mean, stdv, out);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }

@@ -47,6 +47,7 @@ def _load():
         "shm_vae_plan_workspace_bytes": (C.c_size_t, [vp]),
         "shm_vae_pack_weights": (C.c_int, [vp, f32p, vp, vp]),
         "shm_vae_forward": (C.c_int, [vp, f32p, f32p, f32p, f32p, f32p, f32p, C.c_int32, C.c_uint64, vp, vp]),
+        "shm_window_gather": (C.c_int, [vp, C.c_int64, C.c_int32, vp, C.c_int32, C.c_int32, vp, vp, vp, vp]),
         "shm_vae_plan_status": (C.c_int, [vp, vp, vp]),
         "shm_set_pair_launch": (C.c_int, [C.c_int]),
         "shm_vae_loss": (C.c_int, [vp, f32p, C.c_float, f32p, vp, vp]),

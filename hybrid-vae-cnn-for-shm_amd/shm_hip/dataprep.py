@@ -105,3 +105,62 @@ def select_channels(X: np.ndarray, idx):
     if max(idx) >= X.shape[2]:
         raise ValueError(f"CHANNELS_IDX out of range for C={X.shape[2]}.")
     return X[:, :, idx], idx
+
+
+# ---- on-device windowing: the raw series stays on the device, windows are gathered by libshm_hip.so
+def device_windows(series, starts, win_len: int, mean=None, std=None):
+    """Z-scored windows [N, win_len, D] (device fp32) of a device series [n_rows, D]: row block starts[n] .. starts[n]+win_len-1 each,
+    (x - mean) / std, NaN/inf -> 0 — make_windows + normalize_windows (03_train_vae.py:98-117) without the win_len-fold host copy.
+    `starts` may be a list / numpy array (validated here) or an int32 device tensor (validated with one reduction)."""
+    import ctypes as C
+
+    import torch
+
+    from ._capi import check, lib
+    if series.device.type != "cuda" or series.dtype != torch.float32 or series.dim() != 2:
+        raise RuntimeError("device_windows: series must be a 2-D fp32 CUDA tensor (there is no CPU path)")
+    series = series.contiguous()
+    n_rows, D = series.shape
+    if not torch.is_tensor(starts):
+        starts = torch.as_tensor(np.asarray(starts, dtype=np.int64))
+    if starts.numel() and (int(starts.min()) < 0 or int(starts.max()) > n_rows - win_len):
+        raise ValueError(f"device_windows: window starts must lie in [0, {n_rows - win_len}]")
+    st = starts.to(device=series.device, dtype=torch.int32).contiguous()
+    N = int(st.numel())
+    out = torch.empty(N, win_len, D, dtype=torch.float32, device=series.device)
+    if N == 0:
+        return out
+    mp = sp = None
+    if mean is not None:
+        mt = torch.as_tensor(np.asarray(mean, dtype=np.float32)).to(series.device) if not torch.is_tensor(mean) else mean.to(series.device, torch.float32)
+        stt = torch.as_tensor(np.asarray(std, dtype=np.float32)).to(series.device) if not torch.is_tensor(std) else std.to(series.device, torch.float32)
+        mp, sp = C.c_void_p(mt.data_ptr()), C.c_void_p(stt.data_ptr())
+    check(lib.shm_window_gather(C.c_void_p(series.data_ptr()), C.c_int64(n_rows), D, C.c_void_p(st.data_ptr()) if N else None, N, win_len,
+                                mp, sp, C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "shm_window_gather")
+    return out
+
+
+# ---- 1_DOF evaluation helpers (1_DOF/Scripts/datasets.py:38-71)
+def stitch_windows(windows: np.ndarray, full_len: int, stride: int = 1) -> np.ndarray:
+    """Average the overlapping sliding-window reconstructions back into one series [full_len, F] (fp64, as the reference)."""
+    N, seq_len, F = windows.shape
+    out = np.zeros((full_len, F), dtype=float)
+    cnt = np.zeros((full_len, 1), dtype=float)
+    if stride == 1 and N > 0 and N + seq_len - 1 <= full_len:
+        # every window n covers rows n .. n+seq_len-1: accumulate diagonal by diagonal instead of window by window
+        for t in range(seq_len):
+            out[t:t + N] += windows[:, t, :]
+            cnt[t:t + N] += 1.0
+    else:
+        for n in range(N):
+            out[n * stride:n * stride + seq_len] += windows[n]
+            cnt[n * stride:n * stride + seq_len] += 1.0
+    cnt[cnt == 0.0] = 1.0
+    return out / cnt
+
+
+def segment_rmse(y_true: np.ndarray, y_pred: np.ndarray, segment_len: int) -> np.ndarray:
+    T = y_true.shape[0]
+    S = int(np.ceil(T / segment_len))
+    e2 = (np.asarray(y_pred, dtype=float) - np.asarray(y_true, dtype=float)) ** 2
+    return np.array([float(np.sqrt(np.mean(e2[s * segment_len:min((s + 1) * segment_len, T)]))) for s in range(S)], dtype=float)

@@ -81,6 +81,13 @@ int  shm_vae_forward(shm_vae_plan* plan, const float* x, const float* eps,
                      float* recon, float* mu, float* logvar, float* score,
                      int32_t train_mode, uint64_t drop_seed, void* workspace, void* stream);
 
+/* On-device windowing + normalisation: out[n][t][d] = nan_to_num((series[starts[n]+t][d] - mean[d]) / std[d]),
+ * i.e. make_windows + normalize of 4DOF/Scripts/03_train_vae.py:98-117 (dup. 04:73-110, 05:76-115, 06:91-126) without the T-fold
+ * host copy: series [n_rows, D] fp32 and starts [N] int32 are device buffers; every starts[n] must satisfy
+ * 0 <= starts[n] <= n_rows - T (the caller validates; the kernel clamps rather than read out of bounds).  mean/std [D] may both be NULL. */
+int  shm_window_gather(const float* series, int64_t n_rows, int32_t D, const int32_t* starts, int32_t N, int32_t T,
+                       const float* mean, const float* std, float* out, void* stream);
+
 /* Health of the layer-pipelined launches (bf16 path, 2 layers: both LSTM layers of a stack run in ONE launch, the upper
  * layer consuming the lower layer's h_t a few steps behind through in-launch flags).  Synchronises the stream.  SHM_OK, or
  * SHM_ESTATE if a consumer workgroup ever gave up waiting (results since the last shm_vae_pack_weights are then invalid).

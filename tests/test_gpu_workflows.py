@@ -109,3 +109,26 @@ def test_numbered_scripts_run(root):
         assert r.returncode == 0, r.stderr[-2000:]
     assert (root / "Data/processed/vae_mean.npy").exists() and (root / "Data/processed/vae_threshold.json").exists()
     assert '"confusion"' in r.stdout
+
+
+def test_device_windowing_is_bit_identical_to_host_prep():
+    """shm_window_gather vs dataprep.make_windows + normalize_windows (numpy): same fp32 arithmetic, NaN / +-inf -> 0, arbitrary starts."""
+    from shm_hip import dataprep
+    rng = np.random.default_rng(11)
+    X = rng.standard_normal((700, D)).astype(np.float32) * 3.0 + 1.0
+    X[5, 2] = np.nan; X[77, 0] = np.inf; X[300, 11] = -np.inf
+    W = dataprep.make_windows(X, T, 1)
+    mean, std = dataprep.mean_std_from_windows(np.nan_to_num(W))
+    std[3] = 1e-6                                                  # the std == 0 replacement value of the reference
+    ref = dataprep.normalize_windows(W, mean, std)
+    dev = torch.from_numpy(X).cuda()
+    got = dataprep.device_windows(dev, np.arange(W.shape[0]), T, mean, std)
+    assert got.shape == ref.shape and np.array_equal(got.cpu().numpy(), ref)
+    sel = rng.permutation(W.shape[0])[:37]
+    got = dataprep.device_windows(dev, sel, T, mean, std)
+    assert np.array_equal(got.cpu().numpy(), ref[sel])
+    raw = dataprep.device_windows(dev, sel[:5], T)                 # no normalisation: NaN/inf still scrubbed
+    assert np.array_equal(raw.cpu().numpy(), np.nan_to_num(W[sel[:5]], nan=0.0, posinf=0.0, neginf=0.0))
+    assert dataprep.device_windows(dev, [], T, mean, std).shape == (0, T, D)
+    with pytest.raises(ValueError):
+        dataprep.device_windows(dev, [700 - T + 1], T)

@@ -60,3 +60,19 @@ def test_openlab_standardize_semantics():
     assert Xs.shape == (2, 2, 2) and idx == [2, 0] and Xs[1, 1, 0] == 100.0
     with pytest.raises(ValueError):
         dataprep.select_channels(X, [3])
+
+
+def test_stitch_windows_and_segment_rmse_match_the_reference_loops():
+    """1_DOF/Scripts/datasets.py:38-71 restated literally (window-by-window loops) as the expectation."""
+    from shm_hip import dataprep
+    rng = np.random.default_rng(3)
+    for (N, L, F, full, stride) in ((21, 8, 3, 28, 1), (5, 6, 2, 40, 7), (0, 4, 2, 10, 1), (4, 5, 1, 8, 1)):
+        W = rng.standard_normal((N, L, F))
+        out = np.zeros((full, F)); cnt = np.zeros((full, 1))
+        for n in range(N):
+            out[n * stride:n * stride + L] += W[n]; cnt[n * stride:n * stride + L] += 1.0
+        cnt[cnt == 0.0] = 1.0
+        assert np.allclose(dataprep.stitch_windows(W, full, stride), out / cnt, rtol=0, atol=1e-12)
+    yt, yp = rng.standard_normal((23, 2)), rng.standard_normal((23, 2))
+    exp = [float(np.sqrt(np.mean((yp[i:min(i + 5, 23)] - yt[i:min(i + 5, 23)]) ** 2))) for i in range(0, 23, 5)]
+    assert np.allclose(dataprep.segment_rmse(yt, yp, 5), exp, rtol=0, atol=1e-15)
