@@ -39,3 +39,55 @@ def hybrid_predict(vae, cnn, Z: torch.Tensor, threshold: float, batch: int = 512
         y_pred.index_copy_(0, sel, cls + 1)
         p_struct.index_copy_(0, sel, p1)
     return mse, y_pred, p_struct
+
+
+# ---- batched across the GPUs of a node (SURVEY.md §8e "Inference (config 5)", §8f rank 1): windows are sharded r, r+G, r+2G, ...
+# over the ranks, each rank scores / classifies its shard, and the small result vectors (N fp32 scores, N int64 labels, N fp32
+# probabilities) are gathered so that EVERY rank holds the full result — the percentile threshold and the metrics need all of them.
+# No collective touches window data.  Works on any initialised torch.distributed backend ("nccl" = RCCL on the GPUs, "gloo" in the
+# CPU tests); without an initialised process group it degenerates to the single-GPU functions above.
+def _world(group=None):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist, dist.get_rank(group), dist.get_world_size(group)
+    return None, 0, 1
+
+
+def _gather_sharded(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
+    """local = results of items rank, rank+G, ... ; returns the [n_total] vector in the original item order on every rank."""
+    dist, rank, world = _world(group)
+    if world == 1:
+        return local
+    per = (n_total + world - 1) // world
+    pad = torch.zeros(per, dtype=local.dtype, device=local.device)
+    pad[:local.numel()] = local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    out = torch.empty(n_total, dtype=local.dtype, device=local.device)
+    for r in range(world):
+        n_r = len(range(r, n_total, world))
+        out[r::world] = parts[r][:n_r]
+    return out
+
+
+def score_windows_sharded(vae, Z: torch.Tensor, batch: int = 512, group=None) -> torch.Tensor:
+    """Per-window MSE of ALL N windows, every rank computing N/G of them (04_vae_thresholding.py:113-124 at node scale)."""
+    _, rank, world = _world(group)
+    local = score_windows(vae, Z[rank::world].contiguous(), batch) if world > 1 else score_windows(vae, Z, batch)
+    return _gather_sharded(local, Z.size(0), group)
+
+
+def hybrid_predict_sharded(vae, cnn, Z: torch.Tensor, threshold: float, batch: int = 512, group=None):
+    """hybrid_predict over the ranks of `group`; returns (mse, y_pred, p_struct) of all N windows on every rank."""
+    _, rank, world = _world(group)
+    if world == 1:
+        return hybrid_predict(vae, cnn, Z, threshold, batch)
+    mse, y, p = hybrid_predict(vae, cnn, Z[rank::world].contiguous(), threshold, batch)
+    n = Z.size(0)
+    return _gather_sharded(mse, n, group), _gather_sharded(y, n, group), _gather_sharded(p, n, group)
+
+
+def percentile_threshold(scores: torch.Tensor, percentile: float = 99.0) -> float:
+    """np.percentile(scores, p) (linear interpolation), 04_vae_thresholding.py:283 / openLAB P95 — on the gathered scores."""
+    import numpy as np
+    return float(np.percentile(scores.detach().cpu().numpy(), percentile))
