@@ -91,19 +91,26 @@ __global__ void __launch_bounds__(256) conv3x3_fwd_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------ BatchNorm statistics
-// one block; thread c < C.  train: batch mean / biased var from the per-window partials (fp64 accumulation), running
-// statistics updated with momentum 0.1 and the unbiased variance; eval: running statistics.
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+// grid = C, one wave per channel: lanes stride over the B per-window partials (fp64), then a butterfly — fixed order.
+// train: batch mean / biased var, running statistics updated with momentum 0.1 and the unbiased variance; eval: running statistics.
+// (One thread per channel walking all B partials serially took 126 us per launch at B = 512.)
 __global__ void __launch_bounds__(64) bn_finalize_kernel(int C, int B, long long n_per_channel, int train, const float* __restrict__ part,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float* __restrict__ run_mean, float* __restrict__ run_var,
                                                          float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                          float* __restrict__ scale, float* __restrict__ shift) {
-    const int c = threadIdx.x;
-    if (c >= C) return;
+    const int c = blockIdx.x;
     float mean, var;
     if (train) {
         double s = 0.0, q = 0.0;
-        for (int b = 0; b < B; ++b) { s += (double)part[((size_t)b * C + c) * 2]; q += (double)part[((size_t)b * C + c) * 2 + 1]; }
+        for (int b = threadIdx.x; b < B; b += 64) { s += (double)part[((size_t)b * C + c) * 2]; q += (double)part[((size_t)b * C + c) * 2 + 1]; }
+        s = wave_sum_f64(s); q = wave_sum_f64(q);
+        if (threadIdx.x != 0) return;
         const double m = s / (double)n_per_channel;
         double v = q / (double)n_per_channel - m * m;
         if (v < 0.0) v = 0.0;
@@ -112,6 +119,7 @@ __global__ void __launch_bounds__(64) bn_finalize_kernel(int C, int B, long long
         run_mean[c] = 0.9f * run_mean[c] + 0.1f * mean;
         run_var[c] = 0.9f * run_var[c] + 0.1f * (float)unb;
     } else {
+        if (threadIdx.x != 0) return;
         mean = run_mean[c]; var = run_var[c];
     }
     const float rstd = 1.0f / sqrtf(var + 1e-5f);
@@ -143,45 +151,55 @@ __global__ void __launch_bounds__(256) bn_relu_pool_kernel(int C, int H, int W, 
 }
 
 // ------------------------------------------------------------------------------------------------ dense layers
-// out[b][o] = sum_f in[b][f] W[o][f] + bias[o]; optional ReLU (+ pre-activation copy) and dropout.  32x32 tiles.
+// out[b][o] = sum_f in[b][f] W[o][f] + bias[o]; optional ReLU (+ pre-activation copy) and dropout.  Tile = 8 rows x 32 outputs
+// (one output per thread): fc1 at B = 512 is 256 workgroups — the 32 x 32 tiling gave 64 and 112 us per launch.  The F loop is
+// staged 64 wide with the next chunk's global loads issued before the current chunk is consumed.
 __global__ void __launch_bounds__(256) linear_fwd_kernel(int B, int F, int O, const float* __restrict__ in, const float* __restrict__ Wt,
                                                          const float* __restrict__ bias, float* __restrict__ pre, float* __restrict__ out,
                                                          int relu, float drop_p, unsigned long long drop_seed) {
-    __shared__ float sI[32][33];
-    __shared__ float sW[32][33];
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int b0 = blockIdx.y * 32, o0 = blockIdx.x * 32;
-    float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-    for (int f0 = 0; f0 < F; f0 += 32) {
-        for (int e = threadIdx.x; e < 1024; e += 256) {
-            const int r = e >> 5, k = e & 31;
-            sI[r][k] = (b0 + r < B && f0 + k < F) ? in[(size_t)(b0 + r) * F + f0 + k] : 0.f;
-            sW[r][k] = (o0 + r < O && f0 + k < F) ? Wt[(size_t)(o0 + r) * F + f0 + k] : 0.f;
+    constexpr int FC = 64;
+    __shared__ float sI[8][FC + 1];
+    __shared__ float sW[32][FC + 1];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int b0 = blockIdx.y * 8, o0 = blockIdx.x * 32;
+    float acc = 0.f;
+    float ri[2], rw[8];
+    auto load = [&](int f0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = threadIdx.x + i * 256, r = e >> 6, k = e & 63;
+            ri[i] = (b0 + r < B && f0 + k < F) ? in[(size_t)(b0 + r) * F + f0 + k] : 0.f;
         }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = threadIdx.x + i * 256, r = e >> 6, k = e & 63;
+            rw[i] = (o0 + r < O && f0 + k < F) ? Wt[(size_t)(o0 + r) * F + f0 + k] : 0.f;
+        }
+    };
+    load(0);
+    for (int f0 = 0; f0 < F; f0 += FC) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { const int e = threadIdx.x + i * 256; sI[e >> 6][e & 63] = ri[i]; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const int e = threadIdx.x + i * 256; sW[e >> 6][e & 63] = rw[i]; }
         __syncthreads();
-#pragma unroll 8
-        for (int k = 0; k < 32; ++k) {
-            const float i0 = sI[ty][k], i1 = sI[ty + 16][k], w0 = sW[tx][k], w1 = sW[tx + 16][k];
-            acc[0][0] = fmaf(i0, w0, acc[0][0]); acc[0][1] = fmaf(i0, w1, acc[0][1]);
-            acc[1][0] = fmaf(i1, w0, acc[1][0]); acc[1][1] = fmaf(i1, w1, acc[1][1]);
-        }
+        if (f0 + FC < F) load(f0 + FC);
+#pragma unroll 16
+        for (int k = 0; k < FC; ++k) acc = fmaf(sI[ty][k], sW[tx][k], acc);
         __syncthreads();
     }
     const uint32_t thr = drop_threshold(drop_p);
     const float dscale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int jn = 0; jn < 2; ++jn) {
-            const int b = b0 + ty + 16 * i, o = o0 + tx + 16 * jn;
-            if (b < B && o < O) {
-                float v = acc[i][jn] + bias[o];
-                if (pre) pre[(size_t)b * O + o] = v;
-                if (relu) v = fmaxf(v, 0.f);
-                if (drop_p > 0.f) v = drop_hash(drop_seed, 2u, (uint32_t)(b * O + o)) >= thr ? v * dscale : 0.f;
-                out[(size_t)b * O + o] = v;
-            }
+    {
+        const int b = b0 + ty, o = o0 + tx;
+        if (b < B && o < O) {
+            float v = acc + bias[o];
+            if (pre) pre[(size_t)b * O + o] = v;
+            if (relu) v = fmaxf(v, 0.f);
+            if (drop_p > 0.f) v = drop_hash(drop_seed, 2u, (uint32_t)(b * O + o)) >= thr ? v * dscale : 0.f;
+            out[(size_t)b * O + o] = v;
         }
+    }
 }
 
 // dx[b][f] = sum_o dy[b][o] W[o][f]; optional ReLU mask (pre > 0) and dropout mask on the result (fc2 -> fc1 hand-off)
@@ -272,10 +290,11 @@ __global__ void __launch_bounds__(256) bn_bwd_stats_kernel(int C, int H, int W, 
 __global__ void __launch_bounds__(64) bn_bwd_finalize_kernel(int C, int B, long long n_per_channel, const float* __restrict__ part,
                                                              float* __restrict__ k1, float* __restrict__ k2, float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta) {
-    const int c = threadIdx.x;
-    if (c >= C) return;
+    const int c = blockIdx.x;                                  // one wave per channel (see bn_finalize_kernel)
     double s = 0.0, q = 0.0;
-    for (int b = 0; b < B; ++b) { s += (double)part[((size_t)b * C + c) * 2]; q += (double)part[((size_t)b * C + c) * 2 + 1]; }
+    for (int b = threadIdx.x; b < B; b += 64) { s += (double)part[((size_t)b * C + c) * 2]; q += (double)part[((size_t)b * C + c) * 2 + 1]; }
+    s = wave_sum_f64(s); q = wave_sum_f64(q);
+    if (threadIdx.x != 0) return;
     dbeta[c] = (float)s; dgamma[c] = (float)q;
     k1[c] = (float)(s / (double)n_per_channel); k2[c] = (float)(q / (double)n_per_channel);
 }
@@ -347,26 +366,63 @@ __global__ void __launch_bounds__(256) conv3x3_bwd_weight_kernel(const float* __
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int HW = H * W, b = blockIdx.x, tid = threadIdx.x;
     constexpr int NW_ = COUT * CIN * 9;
+    const int XS = HW + 1;           // odd row stride: the lanes of a wave walk different ci rows -> different banks
     float* ds = sm;                  // [COUT][HW]
-    float* xs = sm + COUT * HW;      // [CIN][HW]
+    float* xs = sm + COUT * HW;      // [CIN][HW + 1]
     for (int e = tid; e < COUT * HW; e += 256) ds[e] = dy[(size_t)b * COUT * HW + e];
-    for (int e = tid; e < CIN * HW; e += 256) xs[e] = x[(size_t)b * CIN * HW + e];
+    for (int e = tid; e < CIN * HW; e += 256) { const int ci = e / HW; xs[ci * XS + (e - ci * HW)] = x[(size_t)b * CIN * HW + e]; }
     __syncthreads();
     float* out = part + (size_t)b * (NW_ + COUT);
-    for (int e = tid; e < NW_ + COUT; e += 256) {
-        float acc = 0.f;
-        if (e < NW_) {
-            const int co = e / (CIN * 9), r = e - co * CIN * 9, ci = r / 9, k = r - ci * 9, dh = k / 3 - 1, dw = k % 3 - 1;
+    // one (co, ci) pair per thread and pass: the 9 taps share every dy value and a 3-row window of x, so a tap costs about one
+    // LDS read instead of two (the one-tap-per-thread form spent 312 us per launch on conv2 at B = 512).  With fewer pairs than
+    // threads (conv1: 32) the rows are dealt over SL slices per pair and the slice sums combined in a fixed order.
+    constexpr int PAIRS = COUT * CIN, SL = PAIRS >= 256 ? 1 : 256 / PAIRS;
+    float* red = xs + CIN * XS;      // [SL][PAIRS][9] (SL > 1 only)
+    for (int e0 = 0; e0 < PAIRS; e0 += 256 / SL) {
+        const int e = e0 + tid % (256 / SL), slice = tid / (256 / SL);
+        float acc[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc[k] = 0.f;
+        if (e < PAIRS) {
+            const int co = e / CIN, ci = e - co * CIN;
             const float* dr = ds + co * HW;
-            const float* xr = xs + ci * HW;
-            const int h_lo = dh < 0 ? 1 : 0, h_hi = dh > 0 ? H - 1 : H, w_lo = dw < 0 ? 1 : 0, w_hi = dw > 0 ? W - 1 : W;
-            for (int h = h_lo; h < h_hi; ++h)
-                for (int w2 = w_lo; w2 < w_hi; ++w2) acc = fmaf(dr[h * W + w2], xr[(h + dh) * W + w2 + dw], acc);
-        } else {
-            const float* dr = ds + (e - NW_) * HW;
-            for (int p = 0; p < HW; ++p) acc += dr[p];
+            const float* xr = xs + ci * XS;
+            for (int h = slice; h < H; h += SL) {
+                const bool up = h > 0, dn = h + 1 < H;
+                for (int w2 = 0; w2 < W; ++w2) {
+                    const float d = dr[h * W + w2];
+                    const bool lf = w2 > 0, rt = w2 + 1 < W;
+                    const float* xc = xr + h * W + w2;
+                    // tap k = (dh+1)*3 + (dw+1) pairs dy[h][w] with x[h+dh][w+dw]
+                    if (up) { if (lf) acc[0] = fmaf(d, xc[-W - 1], acc[0]); acc[1] = fmaf(d, xc[-W], acc[1]); if (rt) acc[2] = fmaf(d, xc[-W + 1], acc[2]); }
+                    if (lf) acc[3] = fmaf(d, xc[-1], acc[3]);
+                    acc[4] = fmaf(d, xc[0], acc[4]);
+                    if (rt) acc[5] = fmaf(d, xc[1], acc[5]);
+                    if (dn) { if (lf) acc[6] = fmaf(d, xc[W - 1], acc[6]); acc[7] = fmaf(d, xc[W], acc[7]); if (rt) acc[8] = fmaf(d, xc[W + 1], acc[8]); }
+                }
+            }
+            if (SL == 1) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) out[e * 9 + k] = acc[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) red[(slice * PAIRS + e) * 9 + k] = acc[k];
+            }
         }
-        out[e] = acc;
+    }
+    if (SL > 1) {
+        __syncthreads();
+        for (int i = tid; i < PAIRS * 9; i += 256) {
+            float v = 0.f;
+            for (int sl = 0; sl < SL; ++sl) v += red[sl * PAIRS * 9 + i];
+            out[i] = v;
+        }
+    }
+    for (int e = tid; e < COUT; e += 256) {               // bias gradient of this window
+        const float* dr = ds + e * HW;
+        float acc = 0.f;
+        for (int p = 0; p < HW; ++p) acc += dr[p];
+        out[NW_ + e] = acc;
     }
 }
 
@@ -401,7 +457,7 @@ int cnn_conv_fwd(int layer, int B, int H, int W, const float* x, const float* w,
 }
 int cnn_bn_finalize(int C, int B, long long n, int train, const float* part, const float* gamma, const float* beta, float* run_mean,
                     float* run_var, float* mean, float* rstd, float* scale, float* shift, hipStream_t s) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, s, C, B, n, train, part, gamma, beta, run_mean, run_var, mean, rstd, scale, shift);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, s, C, B, n, train, part, gamma, beta, run_mean, run_var, mean, rstd, scale, shift);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
@@ -412,7 +468,7 @@ int cnn_bn_relu_pool(int B, int C, int H, int W, const float* y, const float* sc
 }
 int cnn_linear_fwd(int B, int F, int O, const float* in, const float* Wt, const float* bias, float* pre, float* out, int relu, float drop_p,
                    uint64_t seed, hipStream_t s) {
-    hipLaunchKernelGGL(linear_fwd_kernel, dim3(ceil_div(O, 32), ceil_div(B, 32)), dim3(256), 0, s, B, F, O, in, Wt, bias, pre, out, relu, drop_p,
+    hipLaunchKernelGGL(linear_fwd_kernel, dim3(ceil_div(O, 32), ceil_div(B, 8)), dim3(256), 0, s, B, F, O, in, Wt, bias, pre, out, relu, drop_p,
                        (unsigned long long)seed);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
@@ -443,7 +499,7 @@ int cnn_bn_bwd(int B, int C, int H, int W, const float* dp, const unsigned char*
                const float* gamma, float* part, float* k1, float* k2, float* dgamma, float* dbeta, float* dy, hipStream_t s) {
     hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(B), dim3(256), 0, s, C, H, W, dp, idx, y, mean, rstd, part);
     SHM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(64), 0, s, C, B, (long long)B * H * W, part, k1, k2, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, C, B, (long long)B * H * W, part, k1, k2, dgamma, dbeta);
     SHM_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(B), dim3(256), 0, s, C, H, W, dp, idx, y, mean, rstd, gamma, k1, k2, dy);
     SHM_LAUNCH_CHECK();
@@ -460,11 +516,11 @@ int cnn_conv_bwd_data2(int B, int H, int W, const float* dy, const float* w, flo
 int cnn_conv_bwd_weight(int layer, int B, int H, int W, const float* dy, const float* x, float* part, hipStream_t s) {
     int rc;
     if (layer == 1) {
-        const size_t lds = sizeof(float) * ((size_t)(16 + 2) * H * W);
+        const size_t lds = sizeof(float) * ((size_t)(16 + 2) * H * W + 2 + 8 * 32 * 9);
         if ((rc = opt_in_lds(conv3x3_bwd_weight_kernel<2, 16>, lds))) return rc;
         hipLaunchKernelGGL((conv3x3_bwd_weight_kernel<2, 16>), dim3(B), dim3(256), lds, s, dy, x, part, H, W);
     } else {
-        const size_t lds = sizeof(float) * ((size_t)(32 + 16) * H * W);
+        const size_t lds = sizeof(float) * ((size_t)(32 + 16) * H * W + 16);
         if ((rc = opt_in_lds(conv3x3_bwd_weight_kernel<16, 32>, lds))) return rc;
         hipLaunchKernelGGL((conv3x3_bwd_weight_kernel<16, 32>), dim3(B), dim3(256), lds, s, dy, x, part, H, W);
     }
