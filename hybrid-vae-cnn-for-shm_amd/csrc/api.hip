@@ -691,12 +691,12 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
 }
 
 extern "C" int shm_window_gather(const float* series, int64_t n_rows, int32_t D, const int32_t* starts, int32_t N, int32_t T,
-                                 const float* mean, const float* stdv, float* out, void* stream) {
+                                 const float* mean, const float* stdv, float clip_z, float* out, void* stream) {
     SHM_REQUIRE(series && ((out && starts) || N == 0), SHM_EINVAL, "window_gather: NULL series, starts or out");
     SHM_REQUIRE(n_rows >= 1 && D >= 1 && N >= 0 && T >= 1 && T <= n_rows, SHM_EINVAL, "window_gather: bad shape (rows=%lld D=%d N=%d T=%d)",
                 (long long)n_rows, D, N, T);
     SHM_REQUIRE((mean == nullptr) == (stdv == nullptr), SHM_EINVAL, "window_gather: pass both mean and std or neither");
-    return launch_window_gather(series, n_rows, D, starts, N, T, mean, stdv, out, (hipStream_t)stream);
+    return launch_window_gather(series, n_rows, D, starts, N, T, mean, stdv, clip_z, out, (hipStream_t)stream);
 }
 
 extern "C" int shm_profile_begin(void) {

@@ -1,0 +1,260 @@
+// cnn_openlab.hip — the openLAB fault classifier, inference (eval) forward, fp32; gfx950.
+// Reference: 20250506_openLAB_tests/Codes/Models/cnn_model.py:14-62 —
+//   block(cin, cout, kt, 3, pad (kt/2, 1)) = Conv2d -> GroupNorm(8, eps 1e-5) -> SiLU;  features = block(C,32,7) MaxPool(2,1)
+//   block(32,64,5) MaxPool(2,1) block(64,128,5) MaxPool(2,1) block(128,256,3) AdaptiveAvgPool(1,1);
+//   classifier = Linear(256,128) SiLU Dropout Linear(128, num_classes)            (Dropout is the identity in eval mode)
+// Used by the hybrid VAE-threshold -> CNN inference of the openLAB windows (BASELINE config 5).
+//
+// One workgroup per window and block.  GroupNorm needs the statistics of a whole (group, window) slab before anything can be
+// normalised, so a block is three passes of the same workgroup over a per-window scratch slab that stays in L2/MALL:
+//   1. direct convolution (im2col-free): a thread owns 8 consecutive output channels of one output position; the weights
+//      are re-laid [ci][dt][df][co] once per call so that those 8 channels are two 16-byte broadcast loads;
+//   2. per-group mean / rstd (one wave per two groups, fp64 accumulation, fixed order);
+//   3. normalise + affine + SiLU + MaxPool(2,1) into the next block's input — or, in the last block, the global average
+//      and the two dense layers (256 -> 128 -> classes), all in the same workgroup.
+// fp32 VALU throughout (the parity bar is 1e-4 on the logits; measured ~1e-6); not yet an MFMA kernel.
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace shm {
+
+namespace {
+
+constexpr int OL_GROUPS = 8, OL_CC = 8;     // GroupNorm groups; output channels per thread in the convolution
+
+__device__ __forceinline__ float silu(float v) { return v / (1.0f + expf(-v)); }
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// w [COUT][CIN][KT][3] -> wt [CIN][KT][3][COUT]
+__global__ void __launch_bounds__(256) ol_weight_relayout_kernel(const float* __restrict__ w, float* __restrict__ wt, int COUT, int CK) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < COUT * CK) { const int co = i / CK, r = i - co * CK; wt[(size_t)r * COUT + co] = w[i]; }
+}
+
+struct OlHead { const float* w1; const float* b1; const float* w2; const float* b2; float* logits; int NC; };
+
+// in [B][CIN][H][W], y scratch [B][COUT][H][W], out [B][COUT][H/2][W] (POOL) or logits (LAST)
+template <bool LAST>
+__global__ void __launch_bounds__(256) ol_block_kernel(const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
+                                                       float* __restrict__ out, int CIN, int COUT, int KT, int H, int W, OlHead hd) {
+    __shared__ float g_mean[OL_GROUPS], g_rstd[OL_GROUPS];
+    __shared__ float feat[256], hid[128];
+    const int b = blockIdx.x, tid = threadIdx.x, HW = H * W, PT = KT / 2;
+    const float* xin = in + (size_t)b * CIN * HW;
+    float* yb = y + (size_t)b * COUT * HW;
+
+    // ---- pass 1: convolution + bias
+    const int chunks = COUT / OL_CC;
+    for (int item = tid; item < HW * chunks; item += 256) {
+        const int ch = item / HW, p = item - ch * HW, h = p / W, w0 = p - h * W, co0 = ch * OL_CC;
+        float acc[OL_CC];
+#pragma unroll
+        for (int k = 0; k < OL_CC; ++k) acc[k] = bias[co0 + k];
+        for (int ci = 0; ci < CIN; ++ci) {
+            const float* xc = xin + (size_t)ci * HW;
+            for (int dt = 0; dt < KT; ++dt) {
+                const int hh = h + dt - PT;
+                if (hh < 0 || hh >= H) continue;
+#pragma unroll
+                for (int df = 0; df < 3; ++df) {
+                    const int ww = w0 + df - 1;
+                    if (ww < 0 || ww >= W) continue;
+                    const float xv = xc[hh * W + ww];
+                    const float* wr = wt + ((size_t)(ci * KT + dt) * 3 + df) * COUT + co0;
+                    const f32x4 wa = *reinterpret_cast<const f32x4*>(wr), wb = *reinterpret_cast<const f32x4*>(wr + 4);
+                    acc[0] = fmaf(xv, wa[0], acc[0]); acc[1] = fmaf(xv, wa[1], acc[1]); acc[2] = fmaf(xv, wa[2], acc[2]); acc[3] = fmaf(xv, wa[3], acc[3]);
+                    acc[4] = fmaf(xv, wb[0], acc[4]); acc[5] = fmaf(xv, wb[1], acc[5]); acc[6] = fmaf(xv, wb[2], acc[6]); acc[7] = fmaf(xv, wb[3], acc[7]);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < OL_CC; ++k) yb[(size_t)(co0 + k) * HW + p] = acc[k];
+    }
+    __syncthreads();
+
+    // ---- pass 2: GroupNorm statistics (biased variance), wave w -> groups 2w, 2w+1
+    {
+        const int wv = tid >> 6, lane = tid & 63, cg = COUT / OL_GROUPS, n = cg * HW;
+        for (int g = wv * 2; g < wv * 2 + 2; ++g) {
+            const float* yg = yb + (size_t)g * n;
+            double s = 0.0, q = 0.0;
+            for (int i = lane; i < n; i += 64) { const double v = (double)yg[i]; s += v; q += v * v; }
+            s = wave_sum_f64(s); q = wave_sum_f64(q);
+            if (lane == 0) {
+                const double m = s / n;
+                double var = q / n - m * m;
+                if (var < 0.0) var = 0.0;
+                g_mean[g] = (float)m; g_rstd[g] = (float)(1.0 / sqrt(var + 1e-5));
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- pass 3: normalise + affine + SiLU, then MaxPool(2,1) or the head
+    const int cg = COUT / OL_GROUPS;
+    if constexpr (!LAST) {
+        const int Hp = H / 2;
+        float* ob = out + (size_t)b * COUT * Hp * W;
+        for (int e = tid; e < COUT * Hp * W; e += 256) {
+            const int co = e / (Hp * W), r = e - co * Hp * W, hp = r / W, w0 = r - hp * W, g = co / cg;
+            const float sc = gamma[co] * g_rstd[g], sh = beta[co] - g_mean[g] * sc;
+            const float v0 = silu(fmaf(yb[(size_t)co * HW + (2 * hp) * W + w0], sc, sh));
+            const float v1 = silu(fmaf(yb[(size_t)co * HW + (2 * hp + 1) * W + w0], sc, sh));
+            ob[e] = fmaxf(v0, v1);
+        }
+    } else {
+        // AdaptiveAvgPool(1,1): one channel per thread (COUT == 256), fixed order
+        for (int co = tid; co < COUT; co += 256) {
+            const int g = co / cg;
+            const float sc = gamma[co] * g_rstd[g], sh = beta[co] - g_mean[g] * sc;
+            float s = 0.f;
+            for (int p = 0; p < HW; ++p) s += silu(fmaf(yb[(size_t)co * HW + p], sc, sh));
+            feat[co] = s / (float)HW;
+        }
+        __syncthreads();
+        if (tid < 128) {
+            float a = hd.b1[tid];
+            for (int c = 0; c < 256; ++c) a = fmaf(feat[c], hd.w1[(size_t)tid * 256 + c], a);
+            hid[tid] = silu(a);
+        }
+        __syncthreads();
+        if (tid < hd.NC) {
+            float a = hd.b2[tid];
+            for (int j = 0; j < 128; ++j) a = fmaf(hid[j], hd.w2[(size_t)tid * 128 + j], a);
+            hd.logits[(size_t)b * hd.NC + tid] = a;
+        }
+    }
+}
+
+struct OlBlock { int cin, cout, kt; };
+void ol_blocks(int in_ch, OlBlock (&bl)[4]) { bl[0] = {in_ch, 32, 7}; bl[1] = {32, 64, 5}; bl[2] = {64, 128, 5}; bl[3] = {128, 256, 3}; }
+
+bool ol_config_ok(const shm_olcnn_config* c) {
+    if (!c) { set_error("olcnn: config is NULL"); return false; }
+    if (c->in_channels < 1 || c->in_channels > 64) { set_error("olcnn: in_channels %d unsupported (1..64)", c->in_channels); return false; }
+    if (c->num_classes < 1 || c->num_classes > 64) { set_error("olcnn: num_classes %d unsupported (1..64)", c->num_classes); return false; }
+    if (c->seq_len < 8 || c->num_features < 1 || c->num_features > 64) {
+        set_error("olcnn: seq_len %d (>= 8) / num_features %d (1..64) unsupported", c->seq_len, c->num_features); return false; }
+    return true;
+}
+
+int ol_layout(const shm_olcnn_config* c, std::vector<shm_tensor_desc>& out) {
+    OlBlock bl[4];
+    ol_blocks(c->in_channels, bl);
+    int64_t off = 0;
+    auto add = [&](const char* name, int ndim, int s0, int s1, int s2, int s3) {
+        shm_tensor_desc d;
+        memset(&d, 0, sizeof(d));
+        snprintf(d.name, sizeof(d.name), "%s", name);
+        d.offset = off; d.ndim = ndim; d.shape[0] = s0; d.shape[1] = s1; d.shape[2] = s2; d.shape[3] = s3;
+        int64_t n = s0;
+        if (ndim > 1) n *= s1;
+        if (ndim > 2) n *= s2;
+        if (ndim > 3) n *= s3;
+        off = (off + n + 3) & ~(int64_t)3;
+        out.push_back(d);
+    };
+    char nm[48];
+    for (int i = 0; i < 4; ++i) {
+        snprintf(nm, sizeof(nm), "features.%d.0.weight", 2 * i); add(nm, 4, bl[i].cout, bl[i].cin, bl[i].kt, 3);
+        snprintf(nm, sizeof(nm), "features.%d.0.bias", 2 * i); add(nm, 1, bl[i].cout, 0, 0, 0);
+        snprintf(nm, sizeof(nm), "features.%d.1.weight", 2 * i); add(nm, 1, bl[i].cout, 0, 0, 0);
+        snprintf(nm, sizeof(nm), "features.%d.1.bias", 2 * i); add(nm, 1, bl[i].cout, 0, 0, 0);
+    }
+    add("classifier.1.weight", 2, 128, 256, 0, 0); add("classifier.1.bias", 1, 128, 0, 0, 0);
+    add("classifier.4.weight", 2, c->num_classes, 128, 0, 0); add("classifier.4.bias", 1, c->num_classes, 0, 0, 0);
+    return (int)off;
+}
+
+// workspace: re-laid conv weights | y scratch (largest block output) | two ping-pong pooled activations
+struct OlWs { size_t wt[4], y, a0, a1, total; };
+OlWs ol_ws(const shm_olcnn_config* c, int B) {
+    OlBlock bl[4];
+    ol_blocks(c->in_channels, bl);
+    OlWs w;
+    size_t off = 0;
+    auto take = [&](size_t floats) { size_t o = off; off += (floats * sizeof(float) + 255) & ~(size_t)255; return o; };
+    for (int i = 0; i < 4; ++i) w.wt[i] = take((size_t)bl[i].cout * bl[i].cin * bl[i].kt * 3);
+    const size_t HW = (size_t)c->seq_len * c->num_features;
+    w.y = take((size_t)B * 32 * HW);              // every block's pre-pool output is <= 32 * T * W floats per window (channels double, rows halve)
+    w.a0 = take((size_t)B * 32 * (HW / 2 + c->num_features));
+    w.a1 = take((size_t)B * 32 * (HW / 2 + c->num_features));
+    w.total = off;
+    return w;
+}
+
+}  // namespace
+
+}  // namespace shm
+
+using namespace shm;
+
+extern "C" int64_t shm_olcnn_param_count(const shm_olcnn_config* cfg) {
+    if (!ol_config_ok(cfg)) return SHM_EINVAL;
+    std::vector<shm_tensor_desc> v;
+    return ol_layout(cfg, v);
+}
+
+extern "C" int shm_olcnn_param_layout(const shm_olcnn_config* cfg, shm_tensor_desc* out, int max) {
+    if (!ol_config_ok(cfg)) return SHM_EINVAL;
+    std::vector<shm_tensor_desc> v;
+    ol_layout(cfg, v);
+    for (int i = 0; i < (int)v.size() && i < max && out; ++i) out[i] = v[i];
+    return (int)v.size();
+}
+
+extern "C" size_t shm_olcnn_workspace_bytes(const shm_olcnn_config* cfg, int32_t B) {
+    if (!ol_config_ok(cfg) || B < 1) return 0;
+    return ol_ws(cfg, B).total;
+}
+
+extern "C" int shm_olcnn_forward(const shm_olcnn_config* cfg, const float* params, const float* x, float* logits, int32_t B, void* ws, void* stream) {
+    if (!ol_config_ok(cfg)) return SHM_EINVAL;
+    SHM_REQUIRE(params && x && logits && ws && B >= 1, SHM_EINVAL, "olcnn_forward: NULL argument or empty batch");
+    SHM_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255) == 0 && (reinterpret_cast<uintptr_t>(params) & 15) == 0, SHM_EWORKSPACE,
+                "olcnn_forward: workspace must be 256-byte and params 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<shm_tensor_desc> lay;
+    ol_layout(cfg, lay);
+    OlBlock bl[4];
+    ol_blocks(cfg->in_channels, bl);
+    const OlWs w = ol_ws(cfg, B);
+    char* wsb = reinterpret_cast<char*>(ws);
+    auto P = [&](int i) { return params + lay[i].offset; };
+    for (int i = 0; i < 4; ++i) {
+        const int ck = bl[i].cin * bl[i].kt * 3, n = bl[i].cout * ck;
+        hipLaunchKernelGGL(ol_weight_relayout_kernel, dim3((n + 255) / 256), dim3(256), 0, s, P(4 * i), reinterpret_cast<float*>(wsb + w.wt[i]), bl[i].cout, ck);
+        SHM_LAUNCH_CHECK();
+    }
+    OlHead hd;
+    hd.w1 = P(16); hd.b1 = P(17); hd.w2 = P(18); hd.b2 = P(19); hd.logits = logits; hd.NC = cfg->num_classes;
+    const float* in = x;
+    float* y = reinterpret_cast<float*>(wsb + w.y);
+    float* pp[2] = {reinterpret_cast<float*>(wsb + w.a0), reinterpret_cast<float*>(wsb + w.a1)};
+    int H = cfg->seq_len;
+    const int W = cfg->num_features;
+    for (int i = 0; i < 4; ++i) {
+        const float* wt = reinterpret_cast<const float*>(wsb + w.wt[i]);
+        if (i < 3) {
+            hipLaunchKernelGGL(ol_block_kernel<false>, dim3(B), dim3(256), 0, s, in, wt, P(4 * i + 1), P(4 * i + 2), P(4 * i + 3), y, pp[i & 1],
+                               bl[i].cin, bl[i].cout, bl[i].kt, H, W, hd);
+            in = pp[i & 1];
+            H /= 2;
+        } else {
+            SHM_REQUIRE(H >= 1, SHM_EINVAL, "olcnn_forward: seq_len too short");
+            hipLaunchKernelGGL(ol_block_kernel<true>, dim3(B), dim3(256), 0, s, in, wt, P(4 * i + 1), P(4 * i + 2), P(4 * i + 3), y, (float*)nullptr,
+                               bl[i].cin, bl[i].cout, bl[i].kt, H, W, hd);
+        }
+        SHM_LAUNCH_CHECK();
+    }
+    return SHM_OK;
+}

@@ -93,7 +93,7 @@ struct ReduceJob {
 constexpr int MAX_REDUCE_JOBS = 12;
 struct ReduceJobs { ReduceJob job[MAX_REDUCE_JOBS]; int first_block[MAX_REDUCE_JOBS + 1]; int n; };
 int launch_window_gather(const float* series, long long n_rows, int D, const int* starts, int N, int T, const float* mean, const float* stdv,
-                         float* out, hipStream_t s);
+                         float clip_z, float* out, hipStream_t s);
 int reduce_jobs_add(ReduceJobs& j, const float* partial, int nparts, size_t n_out, size_t stride, float* out0, float* out1, int tr_M = 0);
 int launch_reduce_batch(ReduceJobs& jobs, hipStream_t s);
 int launch_gemm_tn_f32(const GemmTnArgs& a, hipStream_t s, ReduceJobs* defer = nullptr);

@@ -458,7 +458,7 @@ __global__ void __launch_bounds__(256) reduce_batch_kernel(ReduceJobs jobs) {
 __global__ void __launch_bounds__(256) window_gather_kernel(const float* __restrict__ series, long long n_rows, int D,
                                                             const int* __restrict__ starts, int N, int T,
                                                             const float* __restrict__ mean, const float* __restrict__ stdv,
-                                                            float* __restrict__ out) {
+                                                            float clip_z, float* __restrict__ out) {
     const size_t per = (size_t)T * D, total = (size_t)N * per;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const size_t n = i / per, r = i - n * per;
@@ -467,6 +467,8 @@ __global__ void __launch_bounds__(256) window_gather_kernel(const float* __restr
         row = row < 0 ? 0 : (row >= n_rows ? n_rows - 1 : row);          // the host wrapper validates; never read out of bounds
         float v = series[(size_t)row * D + d];
         if (mean) v = (v - mean[d]) / stdv[d];
+        // openLAB prep (Codes/04_train_vae.py:113-117): np.clip BEFORE nan_to_num, so +-inf becomes +-clip_z and only NaN becomes 0
+        if (clip_z > 0.f && v == v) v = fminf(fmaxf(v, -clip_z), clip_z);
         out[i] = (v != v || v == INFINITY || v == -INFINITY) ? 0.f : v;  // nan_to_num(nan=0, posinf=0, neginf=0)
     }
 }
@@ -707,11 +709,11 @@ int launch_reduce_partials_strided(const float* partial, int nparts, size_t n, s
     return SHM_OK;
 }
 int launch_window_gather(const float* series, long long n_rows, int D, const int* starts, int N, int T, const float* mean, const float* stdv,
-                         float* out, hipStream_t s) {
+                         float clip_z, float* out, hipStream_t s) {
     if (N == 0) return SHM_OK;
     const size_t total = (size_t)N * T * D;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(window_gather_kernel, dim3(blocks), dim3(256), 0, s, series, n_rows, D, starts, N, T, mean, stdv, out);
+    hipLaunchKernelGGL(window_gather_kernel, dim3(blocks), dim3(256), 0, s, series, n_rows, D, starts, N, T, mean, stdv, clip_z, out);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }

@@ -24,6 +24,10 @@ class CnnConfig(C.Structure):
                 ("num_features", C.c_int32), ("dropout", C.c_float)]
 
 
+class OlCnnConfig(C.Structure):
+    _fields_ = [("in_channels", C.c_int32), ("num_classes", C.c_int32), ("seq_len", C.c_int32), ("num_features", C.c_int32)]
+
+
 class TensorDesc(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("offset", C.c_int64), ("ndim", C.c_int32), ("shape", C.c_int32 * 4)]
 
@@ -47,7 +51,11 @@ def _load():
         "shm_vae_plan_workspace_bytes": (C.c_size_t, [vp]),
         "shm_vae_pack_weights": (C.c_int, [vp, f32p, vp, vp]),
         "shm_vae_forward": (C.c_int, [vp, f32p, f32p, f32p, f32p, f32p, f32p, C.c_int32, C.c_uint64, vp, vp]),
-        "shm_window_gather": (C.c_int, [vp, C.c_int64, C.c_int32, vp, C.c_int32, C.c_int32, vp, vp, vp, vp]),
+        "shm_olcnn_param_count": (C.c_int64, [C.POINTER(OlCnnConfig)]),
+        "shm_olcnn_param_layout": (C.c_int, [C.POINTER(OlCnnConfig), C.POINTER(TensorDesc), C.c_int]),
+        "shm_olcnn_workspace_bytes": (C.c_size_t, [C.POINTER(OlCnnConfig), C.c_int32]),
+        "shm_olcnn_forward": (C.c_int, [C.POINTER(OlCnnConfig), vp, vp, vp, C.c_int32, vp, vp]),
+        "shm_window_gather": (C.c_int, [vp, C.c_int64, C.c_int32, vp, C.c_int32, C.c_int32, vp, vp, C.c_float, vp, vp]),
         "shm_vae_plan_status": (C.c_int, [vp, vp, vp]),
         "shm_set_pair_launch": (C.c_int, [C.c_int]),
         "shm_vae_loss": (C.c_int, [vp, f32p, C.c_float, f32p, vp, vp]),

@@ -108,10 +108,11 @@ def select_channels(X: np.ndarray, idx):
 
 
 # ---- on-device windowing: the raw series stays on the device, windows are gathered by libshm_hip.so
-def device_windows(series, starts, win_len: int, mean=None, std=None):
+def device_windows(series, starts, win_len: int, mean=None, std=None, clip_z: float = 0.0):
     """Z-scored windows [N, win_len, D] (device fp32) of a device series [n_rows, D]: row block starts[n] .. starts[n]+win_len-1 each,
     (x - mean) / std, NaN/inf -> 0 — make_windows + normalize_windows (03_train_vae.py:98-117) without the win_len-fold host copy.
-    `starts` may be a list / numpy array (validated here) or an int32 device tensor (validated with one reduction)."""
+    `starts` may be a list / numpy array (validated here) or an int32 device tensor (validated with one reduction).
+    clip_z > 0: the openLAB variant (z clipped to +-clip_z before the NaN replacement, standardize_openlab above)."""
     import ctypes as C
 
     import torch
@@ -136,7 +137,7 @@ def device_windows(series, starts, win_len: int, mean=None, std=None):
         stt = torch.as_tensor(np.asarray(std, dtype=np.float32)).to(series.device) if not torch.is_tensor(std) else std.to(series.device, torch.float32)
         mp, sp = C.c_void_p(mt.data_ptr()), C.c_void_p(stt.data_ptr())
     check(lib.shm_window_gather(C.c_void_p(series.data_ptr()), C.c_int64(n_rows), D, C.c_void_p(st.data_ptr()) if N else None, N, win_len,
-                                mp, sp, C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "shm_window_gather")
+                                mp, sp, C.c_float(float(clip_z)), C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "shm_window_gather")
     return out
 
 

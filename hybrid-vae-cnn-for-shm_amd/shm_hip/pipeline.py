@@ -91,3 +91,35 @@ def percentile_threshold(scores: torch.Tensor, percentile: float = 99.0) -> floa
     """np.percentile(scores, p) (linear interpolation), 04_vae_thresholding.py:283 / openLAB P95 — on the gathered scores."""
     import numpy as np
     return float(np.percentile(scores.detach().cpu().numpy(), percentile))
+
+
+# ---- openLAB hybrid inference (20250506_openLAB_tests/Codes/10_test_hybrid_pipeline.py:241-251, 266-302, 391-409):
+# stage 1: VAE reconstruction MSE on the VAE-standardised windows, anomalous = mse > vae_thr; stage 2: the anomalous windows,
+# standardised with the CNN's own statistics, go through the openLAB classifier as [n, 1, T, F]; prob_st = softmax[:, 1];
+# structural-fault iff prob_st >= cnn_thr.  Labels: 0 normal, 1 sensor fault (SF), 2 structural fault (ST).
+@torch.no_grad()
+def hybrid_predict_openlab(vae, cnn, Z_vae: torch.Tensor, X_cnn: torch.Tensor, vae_thr: float, cnn_thr: float, batch: int = 512):
+    """Z_vae [N,T,Dv], X_cnn [N,T,F]: device tensors already standardised for the VAE / the CNN (dataprep.standardize_openlab or
+    dataprep.device_windows(..., clip_z=...)).  Returns (mse [N], y_pred [N] int64, prob_st [N] fp32, 0 where not anomalous)."""
+    vae.eval(); cnn.eval()
+    N = Z_vae.size(0)
+    mse = score_windows(vae, Z_vae, batch)
+    y_pred = torch.zeros(N, dtype=torch.int64, device=Z_vae.device)
+    prob_st = torch.zeros(N, dtype=torch.float32, device=Z_vae.device)
+    idx = torch.nonzero(mse > vae_thr, as_tuple=False).flatten()
+    for j in range(0, idx.numel(), batch):
+        sel = idx[j:j + batch]
+        logits = cnn(X_cnn.index_select(0, sel).unsqueeze(1))
+        _, p1 = predict(logits)                                   # softmax[:, 1] in libshm_hip.so
+        y_pred.index_copy_(0, sel, 1 + (p1 >= cnn_thr).to(torch.int64))
+        prob_st.index_copy_(0, sel, p1)
+    return mse, y_pred, prob_st
+
+
+def hybrid_predict_openlab_sharded(vae, cnn, Z_vae, X_cnn, vae_thr, cnn_thr, batch: int = 512, group=None):
+    _, rank, world = _world(group)
+    if world == 1:
+        return hybrid_predict_openlab(vae, cnn, Z_vae, X_cnn, vae_thr, cnn_thr, batch)
+    mse, y, p = hybrid_predict_openlab(vae, cnn, Z_vae[rank::world].contiguous(), X_cnn[rank::world].contiguous(), vae_thr, cnn_thr, batch)
+    n = Z_vae.size(0)
+    return _gather_sharded(mse, n, group), _gather_sharded(y, n, group), _gather_sharded(p, n, group)

@@ -84,9 +84,11 @@ int  shm_vae_forward(shm_vae_plan* plan, const float* x, const float* eps,
 /* On-device windowing + normalisation: out[n][t][d] = nan_to_num((series[starts[n]+t][d] - mean[d]) / std[d]),
  * i.e. make_windows + normalize of 4DOF/Scripts/03_train_vae.py:98-117 (dup. 04:73-110, 05:76-115, 06:91-126) without the T-fold
  * host copy: series [n_rows, D] fp32 and starts [N] int32 are device buffers; every starts[n] must satisfy
- * 0 <= starts[n] <= n_rows - T (the caller validates; the kernel clamps rather than read out of bounds).  mean/std [D] may both be NULL. */
+ * 0 <= starts[n] <= n_rows - T (the caller validates; the kernel clamps rather than read out of bounds).  mean/std [D] may both be NULL.
+ * clip_z > 0 adds the openLAB variant's np.clip(z, -clip_z, clip_z) between the z-score and the NaN replacement
+ * (20250506_openLAB_tests/Codes/04_train_vae.py:113-117: +-inf then becomes +-clip_z, only NaN becomes 0); clip_z <= 0: no clip. */
 int  shm_window_gather(const float* series, int64_t n_rows, int32_t D, const int32_t* starts, int32_t N, int32_t T,
-                       const float* mean, const float* std, float* out, void* stream);
+                       const float* mean, const float* std, float clip_z, float* out, void* stream);
 
 /* Health of the layer-pipelined launches (bf16 path, 2 layers: both LSTM layers of a stack run in ONE launch, the upper
  * layer consuming the lower layer's h_t a few steps behind through in-launch flags).  Synchronises the stream.  SHM_OK, or
@@ -166,6 +168,24 @@ void shm_dropout_keep_mask(uint64_t drop_seed, int32_t stack, int32_t B, int32_t
 /* Same for SHM_PREC_BF16 plans, whose sequences live in 16-window tile-blocked row order (the RNG is indexed by the
  * element's position in that layout); keep[] is still written in natural [B,T,H] order. */
 void shm_dropout_keep_mask_tiled(uint64_t drop_seed, int32_t stack, int32_t B, int32_t T, int32_t H, float p, uint8_t* keep);
+
+/* ---- openLAB fault classifier, inference forward (reference 20250506_openLAB_tests/Codes/Models/cnn_model.py:14-62:
+ * 4 x [Conv2d(kt x 3) -> GroupNorm(8) -> SiLU] with MaxPool(2,1) between and AdaptiveAvgPool at the end, Linear(256,128)-SiLU-
+ * Dropout-Linear(128,classes)); eval mode only (Dropout = identity), used by the hybrid VAE-threshold -> CNN inference of
+ * 20250506_openLAB_tests/Codes/10_test_hybrid_pipeline.py:266-302.  Stateless: params is the flat fp32 state_dict in
+ * shm_olcnn_param_layout order (features.{0,2,4,6}.{0,1}.{weight,bias}, classifier.{1,4}.{weight,bias}), x is [B, in_channels,
+ * seq_len, num_features] fp32, logits [B, num_classes]; workspace: shm_olcnn_workspace_bytes, 256-byte aligned, caller-owned. */
+typedef struct shm_olcnn_config {
+    int32_t in_channels;   /* 1 in the reference */
+    int32_t num_classes;   /* 2 */
+    int32_t seq_len;       /* T: 200 in the reference, any length >= 8 (the conv stack is size-agnostic) */
+    int32_t num_features;  /* W: 4 */
+} shm_olcnn_config;
+int64_t shm_olcnn_param_count(const shm_olcnn_config* cfg);
+int     shm_olcnn_param_layout(const shm_olcnn_config* cfg, shm_tensor_desc* out, int max);
+size_t  shm_olcnn_workspace_bytes(const shm_olcnn_config* cfg, int32_t B);
+int     shm_olcnn_forward(const shm_olcnn_config* cfg, const float* params, const float* x, float* logits, int32_t B,
+                          void* workspace, void* stream);
 
 #ifdef __cplusplus
 }

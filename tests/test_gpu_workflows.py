@@ -129,6 +129,11 @@ def test_device_windowing_is_bit_identical_to_host_prep():
     assert np.array_equal(got.cpu().numpy(), ref[sel])
     raw = dataprep.device_windows(dev, sel[:5], T)                 # no normalisation: NaN/inf still scrubbed
     assert np.array_equal(raw.cpu().numpy(), np.nan_to_num(W[sel[:5]], nan=0.0, posinf=0.0, neginf=0.0))
+    # openLAB variant: clip before the NaN replacement (+-inf -> +-clip)
+    mu, sd = dataprep.fit_mean_std_openlab(np.where(np.isfinite(W[:50]), W[:50], np.nan))
+    refo = dataprep.standardize_openlab(W[sel], mu, sd, 2.5)
+    goto = dataprep.device_windows(dev, sel, T, mu, sd, clip_z=2.5)
+    assert np.array_equal(goto.cpu().numpy(), refo) and refo.max() == 2.5
     assert dataprep.device_windows(dev, [], T, mean, std).shape == (0, T, D)
     with pytest.raises(ValueError):
         dataprep.device_windows(dev, [700 - T + 1], T)

@@ -1,0 +1,28 @@
+"""Ad-hoc timing of the inference side (scoring, hybrid gate) at the north-star and openLAB-like shapes; quoted in DESIGN.md."""
+import sys, time
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+for p in (str(ROOT), str(ROOT / "hybrid-vae-cnn-for-shm_amd")):
+    sys.path.insert(0, p)
+import torch
+from Scripts.Models.temporal_vae import TemporalVAE
+from Scripts.Models.cnn_model import CNN
+from shm_hip.pipeline import score_windows, hybrid_predict
+
+def timeit(f, n=10):
+    for _ in range(2): f()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): f()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n
+
+for (N, T, D, H, Z, L, prec) in ((8192, 256, 4, 128, 16, 2, "bf16"), (8192, 256, 4, 128, 16, 2, "fp32"), (8192, 512, 4, 64, 8, 1, "bf16"), (8192, 100, 12, 128, 16, 2, "bf16")):
+    torch.manual_seed(0)
+    vae = TemporalVAE(D, Z, H, L, 0.3, precision=prec).cuda().eval()
+    cnn = CNN(2, 2, 0.5, seq_len=T, num_features=D).cuda().eval()
+    X = torch.randn(N, T, D, device="cuda")
+    n = 3 if prec == "fp32" else 10
+    ds = timeit(lambda: score_windows(vae, X, 512), n)
+    sc = score_windows(vae, X, 512)
+    thr = float(sc.median())
+    dh = timeit(lambda: hybrid_predict(vae, cnn, X, thr, 512), n)
+    print(f"N={N} T={T} D={D} H={H} L={L} {prec}: score {N/ds:,.0f} windows/s ; hybrid gate+CNN (50% anomalous) {N/dh:,.0f} windows/s", flush=True)
