@@ -26,3 +26,13 @@ for (N, T, D, H, Z, L, prec) in ((8192, 256, 4, 128, 16, 2, "bf16"), (8192, 256,
     thr = float(sc.median())
     dh = timeit(lambda: hybrid_predict(vae, cnn, X, thr, 512), n)
     print(f"N={N} T={T} D={D} H={H} L={L} {prec}: score {N/ds:,.0f} windows/s ; hybrid gate+CNN (50% anomalous) {N/dh:,.0f} windows/s", flush=True)
+
+sys.path.insert(0, str(ROOT / "hybrid-vae-cnn-for-shm_amd" / "Codes"))
+from Models.cnn_model import CNN as OlCNN
+for (B, T) in ((512, 200), (512, 512), (2048, 200)):
+    torch.manual_seed(0)
+    m = OlCNN(1, 2, 0.4).cuda().eval()
+    x = torch.randn(B, 1, T, 4, device="cuda")
+    with torch.no_grad():
+        d = timeit(lambda: m(x), 5)
+    print(f"openLAB CNN eval B={B} T={T}: {d*1e3:.3f} ms = {B/d:,.0f} windows/s ({B/d*135e6*T/200/1e12:.2f} TFLOP/s fp32 VALU)", flush=True)
