@@ -34,6 +34,7 @@ namespace {
 
 constexpr int WPT = SHM_WPT;     // windows per workgroup (see lstm_fwd_bf16.hip: quad tiles, one cell per lane)
 constexpr int DLY = 4;           // pair launch: a step's dpre rows are published DLY steps after they were stored
+constexpr int PAIR_GROUP = 128;  // pair launch: tiles per ticket group
 constexpr unsigned SPIN_MAX = 1u << 21;
 
 typedef __attribute__((address_space(1))) unsigned gu32;
@@ -396,14 +397,19 @@ __global__ void __launch_bounds__(4 * H) lstm_bwd_pair_bf16_kernel(LstmBwdPairAr
     int* role_lds = reinterpret_cast<int*>(reinterpret_cast<char*>(smem_b) + p.role_lds_off);
     if (threadIdx.x == 0) *role_lds = (int)__hip_atomic_fetch_add(sync, 1u, SHM_RLX_AGENT);
     __syncthreads();
-    const int role = *role_lds;
+    const int ticket = *role_lds;
     __syncthreads();
-    if (threadIdx.x == 0 && role < tiles) {               // nobody touches the other block in this launch
-        p.sync_other[16 * (1 + role)] = 0u;
-        if (role == 0) p.sync_other[0] = 0u;
+    // ticket groups of PAIR_GROUP tiles: producers first, then their consumers (see lstm_fwd_bf16.hip)
+    const int grp = ticket / (2 * PAIR_GROUP), r = ticket - grp * 2 * PAIR_GROUP, base = grp * PAIR_GROUP;
+    const int ntg = min(PAIR_GROUP, tiles - base);
+    const bool producer = r < ntg;
+    const int tile = base + (producer ? r : r - ntg);
+    if (threadIdx.x == 0 && producer) {                   // nobody touches the other block in this launch
+        p.sync_other[16 * (1 + tile)] = 0u;
+        if (ticket == 0) p.sync_other[0] = 0u;
     }
-    if (role < tiles) lstm_bwd_body<H, DHTOP, true>(p.l1, role, sync + 16 * (1 + role));
-    else lstm_bwd_fused_dx_body<H, DROP>(p.l0, p.l1, role - tiles, sync + 16 * (1 + role - tiles), (gu32*)p.err);
+    if (producer) lstm_bwd_body<H, DHTOP, true>(p.l1, tile, sync + 16 * (1 + tile));
+    else lstm_bwd_fused_dx_body<H, DROP>(p.l0, p.l1, tile, sync + 16 * (1 + tile), (gu32*)p.err);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

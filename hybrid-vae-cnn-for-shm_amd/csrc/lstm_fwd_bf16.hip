@@ -38,6 +38,7 @@ namespace {
 
 constexpr int WPT = SHM_WPT;     // windows per workgroup
 constexpr int DLY = 4;           // pair launch: a step's h_seq rows are published DLY steps after they were stored
+constexpr int PAIR_GROUP = 128;  // pair launch: tiles per ticket group (two workgroups per tile -> 256 CUs)
 constexpr unsigned SPIN_MAX = 1u << 21;   // bounded consumer spin (a safety net: ~1 s); on expiry the err word is set
 
 template <int V> struct IntC { static constexpr int value = V; };
@@ -360,17 +361,22 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_pair_bf16_kernel(LstmFwdPairAr
     int* role_lds = reinterpret_cast<int*>(reinterpret_cast<char*>(smem_b) + p.role_lds_off);
     if (threadIdx.x == 0) *role_lds = (int)__hip_atomic_fetch_add(sync, 1u, SHM_RLX_AGENT);
     __syncthreads();
-    const int role = *role_lds;
+    const int ticket = *role_lds;
     __syncthreads();
-    if (threadIdx.x == 0 && role < tiles) {               // nobody touches the other block in this launch
-        p.sync_other[16 * (1 + role)] = 0u;
-        if (role == 0) p.sync_other[0] = 0u;
+    // tickets are dealt in groups of PAIR_GROUP tiles: first the group's producers, then its consumers, so that with more tiles
+    // than half the CUs a consumer still runs beside its producer (a consumer's producer always holds a smaller ticket)
+    const int grp = ticket / (2 * PAIR_GROUP), r = ticket - grp * 2 * PAIR_GROUP, base = grp * PAIR_GROUP;
+    const int ntg = min(PAIR_GROUP, tiles - base);
+    const bool producer = r < ntg;
+    const int tile = base + (producer ? r : r - ntg);
+    if (threadIdx.x == 0 && producer) {                   // nobody touches the other block in this launch
+        p.sync_other[16 * (1 + tile)] = 0u;
+        if (ticket == 0) p.sync_other[0] = 0u;
     }
-    if (role < tiles) {
-        if constexpr (XF32_0) lstm_fwd_body<H, 1, true, false, false, SAVE, false, true>(p.l0, role, nullptr, sync + 16 * (1 + role), (gu32*)p.err);
-        else lstm_fwd_body<H, H / 32, false, false, true, SAVE, false, true>(p.l0, role, nullptr, sync + 16 * (1 + role), (gu32*)p.err);
+    if (producer) {
+        if constexpr (XF32_0) lstm_fwd_body<H, 1, true, false, false, SAVE, false, true>(p.l0, tile, nullptr, sync + 16 * (1 + tile), (gu32*)p.err);
+        else lstm_fwd_body<H, H / 32, false, false, true, SAVE, false, true>(p.l0, tile, nullptr, sync + 16 * (1 + tile), (gu32*)p.err);
     } else {
-        const int tile = role - tiles;
         lstm_fwd_body<H, H / 32, false, DROP, false, SAVE, true, false>(p.l1, tile, sync + 16 * (1 + tile), nullptr, (gu32*)p.err);
     }
 }

@@ -146,7 +146,8 @@ def test_bf16_layer_pipelined_launch_is_bit_identical(train_mode):
     from shm_hip._capi import lib
     from shm_hip.trainer import VAETrainer
     # incl. degenerate lengths: T < the hand-off delay (4), T < one 4-step dx chunk, a single window
-    for (B, T, H) in ((512, 256, 128), (510, 100, 128), (37, 50, 64), (9, 31, 32), (1, 1, 128), (3, 2, 128), (5, 3, 64), (2, 5, 32), (4, 7, 128)):
+    for (B, T, H) in ((512, 256, 128), (510, 100, 128), (37, 50, 64), (9, 31, 32), (1, 1, 128), (3, 2, 128), (5, 3, 64), (2, 5, 32), (4, 7, 128),
+                      (1100, 20, 128)):      # 275 tiles: three ticket groups, the last one partial
         torch.manual_seed(11)
         m = TemporalVAE(4, 16, H, 2, 0.3, precision="bf16").cuda()
         gen = torch.Generator().manual_seed(B)
