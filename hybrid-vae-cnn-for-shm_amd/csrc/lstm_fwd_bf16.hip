@@ -104,7 +104,7 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int t
     const int xc = tid < NCH ? tid : 0, xjj = xc / (H / 8), xc8 = (xc - xjj * (H / 8)) * 8;
     const int h_img_off = ((xc8 / KQH) * 16 + xjj) * RSH + (xc8 % KQH);
 
-    struct XSlot { unsigned e; float s0; };                // e: one bf16 element (low 16 bits)
+    struct XSlot { unsigned e; float s0; };                // e: the bf16 element in the low half (plain load) or the dword holding it (consumer)
     // bf16 input (layers >= 1): the WPT x H block of a step has exactly NTHR elements, thread <-> element E = tid = jj*H + unit.
     // Every thread moves (and, with dropout, masks) ITS element; staging 16-byte pieces in wave 0 put the masking of all 4H
     // inputs (8 hashes + selects per lane) on one wave's path and every other wave waited for it at the barrier.
@@ -141,7 +141,8 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int t
             X.s0 = reinterpret_cast<const float*>(a.in)[((size_t)xb0 * T + tc) * In + xk0];
         } else if constexpr (CONSUME) {
             wait_for(tc + 1);
-            X.e = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(in_rsrc, (uint32_t)(tc * WPT * H + tid) * 2, 0, 16);
+            // 4-byte sc1 loads (the width the guide's hand-off table is measured for); two threads share a dword
+            X.e = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(in_rsrc, (uint32_t)(tc * WPT * H + (tid & ~1)) * 2, 0, 16);
         } else {
             X.e = reinterpret_cast<const unsigned short*>(a.in)[((size_t)tile * T + tc) * WPT * H + tid];
         }
@@ -156,7 +157,7 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int t
             }
         } else {
             asm volatile("" : "+v"(X.e));
-            float f = __uint_as_float(X.e << 16);
+            float f = CONSUME ? __uint_as_float((tid & 1) ? (X.e & 0xffff0000u) : (X.e << 16)) : __uint_as_float(X.e << 16);
             if (DROP) {     // element index = (tile-blocked row) * H + unit: identical in the backward's dx product and on the host
                 const uint32_t idx = (uint32_t)(((size_t)tile * T + t) * WPT * H + tid);
                 f = drop_hash(a.drop_seed, a.drop_stack, idx) >= thr ? f * dscale : 0.f;
