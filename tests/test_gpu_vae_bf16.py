@@ -203,3 +203,40 @@ def test_bf16_matches_fp32_path_at_degenerate_shapes(shape):
     assert abs(s16[0] - s32[0]) < 2e-3 * max(1.0, abs(s32[0])), (s16, s32)
     assert np.linalg.norm(g16 - g32) < 3e-2 * max(np.linalg.norm(g32), 1e-9), np.linalg.norm(g16 - g32) / np.linalg.norm(g32)
     assert np.abs(r16 - r32).max() < 5e-3
+
+
+def test_bf16_pipelined_handoff_under_memory_load():
+    """The in-launch hand-offs must not depend on timing: repeat the pipelined train step while a second stream streams 512 MB copies
+    through HBM/L2 (uneven load on the CUs' memory queues), and require bit-identity with the one-launch-per-layer result every time."""
+    from Scripts.Models.temporal_vae import TemporalVAE
+    from shm_hip._capi import lib
+    from shm_hip.trainer import VAETrainer
+    B, T, H = 512, 128, 128
+    gen = torch.Generator().manual_seed(77)
+    x = torch.randn(B, T, 4, generator=gen).cuda()
+    eps = torch.randn(B, 16, generator=gen).cuda()
+
+    def one(on):
+        lib.shm_set_pair_launch(on)
+        try:
+            torch.manual_seed(21)
+            m = TemporalVAE(4, 16, H, 2, 0.3, precision="bf16").cuda().train()
+            tr = VAETrainer(m, lr=1e-3, weight_decay=1e-5, max_norm=2.0)
+            st = tr.step(x, 0.3, eps=eps, drop_seed=5).clone()
+            tr.engine.check_status()
+            return st, tr.grads.clone()
+        finally:
+            lib.shm_set_pair_launch(1)
+
+    ref = one(0)
+    side = torch.cuda.Stream()
+    a = torch.empty(128 * 1024 * 1024, dtype=torch.float32, device="cuda")      # 512 MB
+    b = torch.empty_like(a)
+    for rep in range(12):
+        with torch.cuda.stream(side):
+            for _ in range(3 + rep % 4):                                        # varying amounts of background traffic
+                b.copy_(a, non_blocking=True)
+        got = one(1)
+        side.synchronize()
+        for u, v in zip(ref, got):
+            assert torch.equal(u, v), (rep, float((u - v).abs().max()))
