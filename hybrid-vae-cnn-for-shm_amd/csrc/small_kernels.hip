@@ -85,23 +85,28 @@ __global__ void __launch_bounds__(256) head_fwd_kernel(int B, int H, int Z, int 
 }
 
 // ------------------------------------------------------------------------------------------------ head backward
-// Block = 4 windows.  dh0 = dpre_tsum . W_ih(dec0) is the only real work (4H x H weights, L2-resident): the 4H
-// contraction is split over the 4 waves, every weight element is loaded once per block and feeds all 4 windows.
-__global__ void __launch_bounds__(256) head_bwd_kernel(int B, int H, int Z, int layer_norm, const float* __restrict__ dpre_tsum,
+// Block = 4 windows, HB_WAVES = 16 waves.  dh0 = dpre_tsum . W_ih(dec0) is the only real work (4H x H weights, L2-resident): the
+// 4H contraction is split over the 16 waves (32 weight rows each at H = 128; with 4 waves the 128-iteration load/FMA chain made the
+// kernel 37 us), every weight element is loaded once per block and feeds all 4 windows; waves 0..3 then take one window each.
+constexpr int HB_WAVES = 16;
+__global__ void __launch_bounds__(64 * HB_WAVES) head_bwd_kernel(int B, int H, int Z, int layer_norm, const float* __restrict__ dpre_tsum,
                                                        const float* __restrict__ W_ih_dec0, const float* __restrict__ eps,
                                                        const float* __restrict__ d_mu, const float* __restrict__ d_lv,
                                                        HeadParams p, HeadBufs hb) {
     __shared__ float ds[4][4 * HMAX];        // dpre_tsum rows
-    __shared__ float part[4][4][HMAX];       // [m-quarter][window][k]
+    __shared__ float part[HB_WAVES][4][HMAX];   // [m-slice][window][k]
     __shared__ float dl[4][HMAX];            // d(pre-tanh) of fc_latent_to_hidden
     __shared__ float dmz[4][2 * ZMAX];       // dmu | dlv
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int w = wv & 3;                     // window of the per-window phases (waves 0..3 only)
+    const bool rowwave = wv < 4;
     const int row_raw = blockIdx.x * 4 + w;
-    const bool valid = row_raw < B;
-    const int row = valid ? row_raw : B - 1;
+    const bool valid = rowwave && row_raw < B;
+    const int row = row_raw < B ? row_raw : B - 1;
     const int G = 4 * H;
 
-    for (int m = lane; m < G; m += 64) ds[w][m] = dpre_tsum[(size_t)row * G + m];
+    if (rowwave)
+        for (int m = lane; m < G; m += 64) ds[w][m] = dpre_tsum[(size_t)row * G + m];
     __syncthreads();
     {
         float acc[4][HMAX / 64];
@@ -109,9 +114,9 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(int B, int H, int Z, int 
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int i = 0; i < HMAX / 64; ++i) acc[r][i] = 0.f;
-        const int mq = G / 4;
+        const int mq = G / HB_WAVES;
 #pragma unroll 8
-        for (int m = w * mq; m < (w + 1) * mq; ++m) {
+        for (int m = wv * mq; m < (wv + 1) * mq; ++m) {
             float wv[HMAX / 64];
 #pragma unroll
             for (int i = 0; i < HMAX / 64; ++i) { const int k = lane + 64 * i; wv[i] = k < H ? W_ih_dec0[(size_t)m * H + k] : 0.f; }
@@ -125,17 +130,21 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(int B, int H, int Z, int 
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int i = 0; i < HMAX / 64; ++i) { const int k = lane + 64 * i; if (k < H) part[w][r][k] = acc[r][i]; }
+            for (int i = 0; i < HMAX / 64; ++i) { const int k = lane + 64 * i; if (k < H) part[wv][r][k] = acc[r][i]; }
     }
     __syncthreads();
+    if (!rowwave) return;                     // the per-window phases below synchronise waves 0..3 only through wave-local data
     for (int k = lane; k < H; k += 64) {
-        const float acc = (part[0][w][k] + part[1][w][k]) + (part[2][w][k] + part[3][w][k]);
+        float acc = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < HB_WAVES; sl += 4)
+            acc += (part[sl][w][k] + part[sl + 1][w][k]) + (part[sl + 2][w][k] + part[sl + 3][w][k]);
         const float h0 = hb.h0[(size_t)row * H + k];
         const float dp = acc * (1.0f - h0 * h0);
         dl[w][k] = dp;
         if (valid) { hb.dh0[(size_t)row * H + k] = acc; hb.dpre_l2h[(size_t)row * H + k] = dp; }
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();          // dl[w] / dmz[w] are private to wave w: LDS operations of one wave execute in order
     if (lane < Z) {
         float dz = 0.f;
         for (int k = 0; k < H; ++k) dz = fmaf(dl[w][k], p.l2h_w[(size_t)k * Z + lane], dz);
@@ -146,7 +155,7 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(int B, int H, int Z, int 
         dmz[w][lane] = dm; dmz[w][ZMAX + lane] = dv;
         if (valid) { hb.dmu[i] = dm; hb.dlv[i] = dv; }
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();          // dl[w] / dmz[w] are private to wave w: LDS operations of one wave execute in order
     float dxh[HMAX / 64], xh[HMAX / 64], s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < HMAX / 64; ++i) {
@@ -661,7 +670,8 @@ int launch_head_fwd(int B, int H, int Z, int layer_norm, const float* h_last, co
 int launch_head_bwd(int B, int H, int Z, int layer_norm, const float* dpre_tsum, const float* W_ih_dec0, const float* eps,
                     const float* d_mu, const float* d_lv, const HeadParams& p, const HeadBufs& hb, hipStream_t s) {
     SHM_REQUIRE(H <= HMAX && Z <= ZMAX, SHM_EINVAL, "head: H=%d Z=%d unsupported", H, Z);
-    hipLaunchKernelGGL(head_bwd_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, s, B, H, Z, layer_norm, dpre_tsum, W_ih_dec0, eps, d_mu, d_lv, p, hb);
+    SHM_REQUIRE((4 * H) % HB_WAVES == 0, SHM_EINVAL, "head: 4H = %d must be a multiple of %d", 4 * H, HB_WAVES);
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(ceil_div(B, 4)), dim3(64 * HB_WAVES), 0, s, B, H, Z, layer_norm, dpre_tsum, W_ih_dec0, eps, d_mu, d_lv, p, hb);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }

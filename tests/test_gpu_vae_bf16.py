@@ -178,20 +178,22 @@ def test_bf16_layer_pipelined_launch_is_bit_identical(train_mode):
                     assert torch.equal(a, b), (B, T, H, on, float((a - b).abs().max()))
 
 
-@pytest.mark.parametrize("shape", [(1, 1, 128), (3, 2, 128), (5, 3, 64), (2, 5, 32), (4, 7, 128), (6, 13, 64)])
+@pytest.mark.parametrize("shape", [(1, 1, 128), (3, 2, 128), (5, 3, 64), (2, 5, 32), (4, 7, 128), (6, 13, 64), (7, 40, 128, 12), (5, 33, 128, 1),
+                                   (6, 30, 64, 12)])
 def test_bf16_matches_fp32_path_at_degenerate_shapes(shape):
     """The fp32 path is pinned to the reference at the golden shapes; here it is the checker for sequence lengths around the
     kernels' pipeline depths (hand-off delay 4, 4-step dx chunks, prefetch depth 3/4) and for single windows."""
     from Scripts.Models.temporal_vae import TemporalVAE
     from shm_hip.trainer import VAETrainer
-    B, T, H = shape
+    B, T, H = shape[:3]
+    D = shape[3] if len(shape) > 3 else 4              # D = 12 / 1: the fused 16-column dW_ih product of the H = 128 GEMM with Nx != 4
     gen = torch.Generator().manual_seed(1000 + B * 31 + T)
-    x = torch.randn(B, T, 4, generator=gen).cuda()
+    x = torch.randn(B, T, D, generator=gen).cuda()
     eps = torch.randn(B, 8, generator=gen).cuda()
     out = {}
     for prec in ("fp32", "bf16"):
         torch.manual_seed(5)
-        m = TemporalVAE(4, 8, H, 2, 0.0, precision=prec).cuda().train()
+        m = TemporalVAE(D, 8, H, 2, 0.0, precision=prec).cuda().train()
         tr = VAETrainer(m, lr=1e-3, weight_decay=0.0, max_norm=2.0)
         stats = tr.step(x, 0.25, eps=eps).cpu().numpy()
         tr.engine.check_status()
