@@ -249,6 +249,7 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int t
             }
         }
     };
+    u32x4 rec_prev = {0u, 0u, 0u, 0u};
     // X: slot holding x_{t+2}; committed at the end of the step (into the buffer of x_t, whose projection step t-1 consumed)
     // and refilled with x_{t+5}
     auto step = [&](XSlot& X, int t) {
@@ -257,7 +258,25 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int t
         f32x4 acc[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g] = xproj[g];
+        // The recurrent MFMAs (they need only h_{t-1}) are issued with the step's h-independent vector work between them: the
+        // BPTT record of step t-1 (kept in registers across the barrier) and the staging / masking of x_{t+2}.  A wave issues
+        // in order, so vector work placed behind the MFMA block would wait for the matrix pipe, and placed in front of the
+        // barrier (where it used to be) it delayed every wave's arrival.
+        __builtin_amdgcn_sched_barrier(0);
         mma_h(acc, h_lds + cur * HBUF);
+        if constexpr (SAVE) {
+            if (t > 0) sv[(size_t)(t - 1) * NW * 64] = rec_prev;
+        }
+        if constexpr (!CONSTIN) {
+            if (t + 2 < T) x_commit(X, t + 2, cur);
+            x_fetch(X, t + 5);
+        }
+#pragma unroll
+        for (int i = 0; i < 4 * KSH; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA ...
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);     // ... two vector instructions
+        }
+        __builtin_amdgcn_sched_barrier(0);
 
         float gate[4];
         redeal(acc, gate);
@@ -310,18 +329,12 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int t
         __builtin_amdgcn_sched_barrier(0);
         xm(IntC<7>{});
         h_lds[(cur ^ 1) * HBUF + my_h_off] = (bf16_t)h;
-        if constexpr (!CONSTIN) {
-            if (t + 2 < T) x_commit(X, t + 2, cur);
-            x_fetch(X, t + 5);
-        }
-        if constexpr (SAVE) {
+        if constexpr (SAVE) {                              // stored at the start of the next step (or after the loop)
             f32x2 a0 = {gi, gf}, a1 = {gg, go};
-            u32x4 rec;
-            rec[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(a0, bf16x2));
-            rec[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(a1, bf16x2));
-            rec[2] = __float_as_uint(c_prev);
-            rec[3] = __float_as_uint(tc);
-            sv[(size_t)t * NW * 64] = rec;
+            rec_prev[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(a0, bf16x2));
+            rec_prev[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(a1, bf16x2));
+            rec_prev[2] = __float_as_uint(c_prev);
+            rec_prev[3] = __float_as_uint(tc);
         }
         __syncthreads();
     };
@@ -335,6 +348,7 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int t
         step(X1, t + 1);
         step(X2, t + 2);
     }
+    if constexpr (SAVE) sv[(size_t)(T - 1) * NW * 64] = rec_prev;
     h_flush(T - 1, T & 1);                                 // the last image (buffer T&1; its barrier has passed)
     if constexpr (PRODUCE) {
         if (tid < NCH) {
