@@ -482,6 +482,13 @@ extern "C" int shm_vae_loss(shm_vae_plan* p, const float* x, float kl_w, float* 
     return SHM_OK;
 }
 
+extern "C" int shm_vae_eval_loss(const float* mu, const float* logvar, const float* score, int32_t B, int32_t T, int32_t D, int32_t Z,
+                                 float kl_w, float* losses, void* stream) {
+    SHM_REQUIRE(mu && logvar && score && losses && B >= 1 && Z >= 1, SHM_EINVAL, "eval_loss: NULL argument or empty batch");
+    return launch_vae_loss(B, T, D, Z, nullptr, nullptr, mu, logvar, kl_w, nullptr, nullptr, nullptr, const_cast<float*>(score), losses,
+                           (hipStream_t)stream);
+}
+
 extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_recon, const float* d_mu, const float* d_logvar,
                                 float* grads, void* ws, void* stream) {
     int rc = check_ws(p, ws);

@@ -367,8 +367,7 @@ __global__ void __launch_bounds__(256) vae_loss_kernel(int B, int T, int D, int 
         for (int i = threadIdx.x; i < nz; i += 256) {
             const float m = mu[i], l = lv[i], e = expf(l);
             ks += 1.0f + l - m * m - e;
-            d_mu[i] = kz * m;
-            d_lv[i] = -0.5f * kz * (1.0f - e);
+            if (d_mu) { d_mu[i] = kz * m; d_lv[i] = -0.5f * kz * (1.0f - e); }
         }
         for (int i = threadIdx.x; i < B; i += 256) rs += score[i];
         ks = wave_sum(ks); rs = wave_sum(rs);

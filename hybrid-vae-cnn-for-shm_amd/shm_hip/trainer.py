@@ -108,10 +108,11 @@ class VAETrainer:
         B = x.size(0)
         if eps is None:
             eps = torch.randn(B, eng.cfg.latent_dim, dtype=torch.float32, device=x.device, generator=self.gen)
-        _, mu, lv, score, _, _ = eng.forward(x, eps, training_plan=False, train_mode=False, want_score=True, want_recon=False)
-        recon = score.mean()
-        kl = -0.5 * torch.mean(1.0 + lv - mu.pow(2) - lv.exp())
-        return torch.stack([recon + kl_w * kl, recon, kl])
+        _, mu, lv, score, _, xc = eng.forward(x, eps, training_plan=False, train_mode=False, want_score=True, want_recon=False)
+        out = torch.empty(3, dtype=torch.float32, device=x.device)
+        check(lib.shm_vae_eval_loss(_ptr(mu), _ptr(lv), _ptr(score), B, xc.size(1), xc.size(2), eng.cfg.latent_dim, C.c_float(float(kl_w)),
+                                    _ptr(out), _stream()), "shm_vae_eval_loss")
+        return out
 
 
 class CNNTrainer:

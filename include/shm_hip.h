@@ -104,6 +104,11 @@ int  shm_set_pair_launch(int on);
  * dLoss/d(recon,mu,logvar) in the workspace for shm_vae_backward(..., NULL, NULL, NULL, ...). */
 int  shm_vae_loss(shm_vae_plan* plan, const float* x, float kl_w, float* losses, void* workspace, void* stream);
 
+/* Validation-pass loss (03_train_vae.py:284-299, no state, no gradients): from the outputs of an inference forward — mu, logvar [B,Z]
+ * and the per-window score [B] — writes losses[0..2] = {recon + kl_w*kl, recon = mean(score), kl}.  T, D only document the shape. */
+int  shm_vae_eval_loss(const float* mu, const float* logvar, const float* score, int32_t B, int32_t T, int32_t D, int32_t Z,
+                       float kl_w, float* losses, void* stream);
+
 /* loss.backward() (03_train_vae.py:269): BPTT through decoder, head and encoder.  d_recon[B,T,D],
  * d_mu[B,Z], d_logvar[B,Z] are the upstream gradients (all NULL: use those left by shm_vae_loss).
  * grads: flat fp32 buffer, overwritten (zero_grad(set_to_none=True) semantics). */
