@@ -171,6 +171,11 @@ extern "C" int shm_cnn_loss(shm_cnn_plan* p, const int64_t* labels, float* loss,
     return SHM_OK;
 }
 
+extern "C" int shm_cnn_eval_loss(const float* logits, const int64_t* labels, int32_t B, int32_t num_classes, float* loss, void* stream) {
+    SHM_REQUIRE(logits && labels && loss && B >= 1 && num_classes >= 1, SHM_EINVAL, "cnn eval loss: NULL argument or empty batch");
+    return cnn_ce_loss(B, num_classes, logits, (const long long*)labels, nullptr, loss, (hipStream_t)stream);
+}
+
 extern "C" int shm_cnn_backward(shm_cnn_plan* p, const float* params, const float* x, const float* d_logits, float* grads, void* ws, void* stream) {
     int rc = check(p, ws);
     if (rc) return rc;

@@ -231,7 +231,8 @@ __global__ void __launch_bounds__(256) ce_loss_kernel(int B, int NC, const float
         const float lse = mx + logf(se);
         const int yb = (int)labels[b];
         ls += lse - l[yb];
-        for (int c = 0; c < NC; ++c) dlogits[(size_t)b * NC + c] = (expf(l[c] - lse) - (c == yb ? 1.f : 0.f)) / (float)B;
+        if (dlogits)
+            for (int c = 0; c < NC; ++c) dlogits[(size_t)b * NC + c] = (expf(l[c] - lse) - (c == yb ? 1.f : 0.f)) / (float)B;
     }
     const float tot = block_sum(ls, red);
     if (threadIdx.x == 0) *loss = tot / (float)B;

@@ -56,6 +56,7 @@ def _load():
         "shm_olcnn_workspace_bytes": (C.c_size_t, [C.POINTER(OlCnnConfig), C.c_int32]),
         "shm_olcnn_forward": (C.c_int, [C.POINTER(OlCnnConfig), vp, vp, vp, C.c_int32, vp, vp]),
         "shm_window_gather": (C.c_int, [vp, C.c_int64, C.c_int32, vp, C.c_int32, C.c_int32, vp, vp, C.c_float, vp, vp]),
+        "shm_cnn_eval_loss": (C.c_int, [vp, vp, C.c_int32, C.c_int32, vp, vp]),
         "shm_vae_eval_loss": (C.c_int, [vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, vp, vp]),
         "shm_vae_plan_status": (C.c_int, [vp, vp, vp]),
         "shm_set_pair_launch": (C.c_int, [C.c_int]),

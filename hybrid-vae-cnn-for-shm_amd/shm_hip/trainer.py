@@ -160,3 +160,13 @@ class CNNTrainer:
         self.model.conv1[1].num_batches_tracked += 1
         self.model.conv2[1].num_batches_tracked += 1
         return self.stats
+
+    @torch.no_grad()
+    def evaluate(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        """Validation CrossEntropy of 05_train_cnn.py:284-292 (eval-mode forward, running statistics); device scalar."""
+        self.model.eval()
+        logits = self.model(x)
+        out = torch.empty(1, dtype=torch.float32, device=x.device)
+        check(lib.shm_cnn_eval_loss(_ptr(logits), _ptr(y.contiguous().to(torch.int64)), logits.size(0), logits.size(1), _ptr(out), _stream()),
+              "shm_cnn_eval_loss")
+        return out

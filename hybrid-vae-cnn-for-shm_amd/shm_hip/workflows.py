@@ -112,7 +112,6 @@ def train_cnn(Xtr: torch.Tensor, ytr: np.ndarray, Xva: torch.Tensor, yva: np.nda
     model = _cnn_class()(2, 2, dropout, seq_len=Xtr.size(2), num_features=Xtr.size(3)).to(dev)
     tr = CNNTrainer(model, lr=lr, weight_decay=weight_decay, seed=seed)
     yt, yv = torch.from_numpy(ytr.astype(np.int64)).to(dev), torch.from_numpy(yva.astype(np.int64)).to(dev)
-    lossf = torch.nn.CrossEntropyLoss()
     best_val, best_state, no_improve, hist = float("inf"), None, 0, []
     for ep in range(1, epochs + 1):
         model.train()
@@ -122,12 +121,10 @@ def train_cnn(Xtr: torch.Tensor, ytr: np.ndarray, Xva: torch.Tensor, yva: np.nda
             sel = perm[i:i + batch_size]
             loss = float(tr.step(Xtr.index_select(0, sel), yt.index_select(0, sel))[0])
             tot += loss * sel.numel(); n += sel.numel()
-        model.eval()
         vt, vn = 0.0, 0
-        with torch.no_grad():
-            for i in range(0, Xva.size(0), batch_size):
-                logits = model(Xva[i:i + batch_size])
-                vt += float(lossf(logits, yv[i:i + batch_size])) * logits.size(0); vn += logits.size(0)
+        for i in range(0, Xva.size(0), batch_size):
+            nb = min(batch_size, Xva.size(0) - i)
+            vt += float(tr.evaluate(Xva[i:i + batch_size], yv[i:i + batch_size])) * nb; vn += nb
         tr_avg, va_avg = tot / max(n, 1), vt / max(vn, 1)
         hist.append((tr_avg, va_avg))
         log(f"[cnn] epoch {ep:03d}/{epochs} train={tr_avg:.6f} val={va_avg:.6f}")

@@ -153,6 +153,8 @@ int  shm_cnn_forward(shm_cnn_plan* plan, const float* params, float* running, co
                      int32_t train_mode, uint64_t drop_seed, void* workspace, void* stream);
 /* nn.CrossEntropyLoss() (05_train_cnn.py:257,274): loss (device, 1 float) and dLoss/dlogits left in the workspace. */
 int  shm_cnn_loss(shm_cnn_plan* plan, const int64_t* labels, float* loss, void* workspace, void* stream);
+/* Validation CrossEntropy (05_train_cnn.py:284-292): mean over the batch of -log softmax(logits)[label]; stateless, no gradient. */
+int  shm_cnn_eval_loss(const float* logits, const int64_t* labels, int32_t B, int32_t num_classes, float* loss, void* stream);
 /* loss.backward() (05_train_cnn.py:275).  d_logits NULL: use the one left by shm_cnn_loss.  grads: flat fp32, overwritten. */
 int  shm_cnn_backward(shm_cnn_plan* plan, const float* params, const float* x, const float* d_logits, float* grads,
                       void* workspace, void* stream);
