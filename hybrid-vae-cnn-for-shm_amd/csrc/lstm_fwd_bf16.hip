@@ -263,7 +263,9 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int t
         // in order, so vector work placed behind the MFMA block would wait for the matrix pipe, and placed in front of the
         // barrier (where it used to be) it delayed every wave's arrival.
         __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);                     // the recurrent MFMAs are the critical path of both waves of a SIMD
         mma_h(acc, h_lds + cur * HBUF);
+        __builtin_amdgcn_s_setprio(0);
         if constexpr (SAVE) {
             if (t > 0) sv[(size_t)(t - 1) * NW * 64] = rec_prev;
         }
