@@ -197,7 +197,11 @@ def main():
     trainer.engine.check_status()          # raises if an in-launch layer hand-off ever timed out (results would be invalid)
 
     # per-kernel durations with HIP events on the launch stream (outside the timed region)
+    # EVERY rank runs these steps (a step contains the gradient all-reduce, a collective); only rank 0 records events
     roof = None
+    if args.profile_steps > 0 and rank != 0:
+        run(args.warmup + args.steps, args.profile_steps)
+        torch.cuda.synchronize()
     if rank == 0 and args.profile_steps > 0:
         check(lib.shm_profile_begin(), "shm_profile_begin")
         run(args.warmup + args.steps, args.profile_steps)
