@@ -153,11 +153,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 through torch.distributed.run")
+    # Rehearsal knobs for a ONE-GPU box (never set by the driver): SHM_BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0 and
+    # SHM_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device), so the N > 1 control flow can be exercised.
+    if os.environ.get("SHM_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("SHM_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     torch.manual_seed(42)
     model = TemporalVAE(D, Z, H, L, 0.3, precision=args.precision).to(dev).train()
