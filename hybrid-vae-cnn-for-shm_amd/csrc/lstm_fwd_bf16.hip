@@ -8,18 +8,22 @@
 //   * wave w owns hidden units [16w,16w+16) x gates i,f,g,o; W_hh and W_ih fragments live in REGISTERS for the whole
 //     sequence (64 VGPRs per matrix per wave at H = 128); the MFMA computes gates^T[64 x 16] = W . [h|x]^T with the 4 windows
 //     in columns 0..3 of the B operand (columns 4..15 are zero rows of the LDS image);
-//   * the accumulator (lane (q,j) = units 4q..4q+3 of window j, only j < 4 meaningful) is re-dealt through a 1 KiB per-wave
-//     LDS scratch so that EVERY lane owns exactly one cell: lane (q,jj) = unit 4q + (jj>>2) of window jj&3.  The cell update
-//     (5 transcendentals) then costs a quarter of the VALU issue of the 16-window mapping, and c_t is one register;
+//   * the accumulator (lane (q,j) = units 4q..4q+3 of window j, only j < 4 meaningful) is re-dealt with DPP row shifts so
+//     that EVERY lane owns exactly one cell: lane (q,jj) = unit 4q + (jj>>2) of window jj&3.  The cell update (10
+//     transcendental instructions) then costs a quarter of the VALU issue of the 16-window mapping, and c_t is one register;
 //   * saved state for BPTT is ONE 16-byte record per lane per step {i,f | g,o (bf16), c_{t-1}, tanh(c_t) (fp32)} in
-//     fragment order (1 KiB contiguous per wave);
+//     fragment order (1 KiB contiguous per wave), stored at the start of the NEXT step, behind the MFMA issue;
 //   * h_t returns to the LDS operand image as bf16; h_seq is tile-blocked row-major (row r' = (tile*T + t)*4 + j) and is
-//     copied out of the completed image one step later as 16-byte coalesced stores; the next layer stages x_t from the same
-//     contiguous 4 x H block;
-//   * x_{t+1..t+3} are prefetched in three rotating register slots; the time loop is branch-free (clamped loads, T % 3
-//     steps peeled, slot use pinned with an empty asm) so the compiler emits one counted s_waitcnt vmcnt per step.
-//     (Issuing W_ih x_{t+1} at the end of step t, ahead of the barrier, was measured SLOWER — 0.29 vs 0.27 ms per layer-1
-//     launch: the two waves of a SIMD share its MFMA pipe, so the extra MFMAs only delay the barrier arrival.)
+//     copied out of the completed image one step later as 16-byte coalesced stores;
+//   * the layer input of a bf16 layer is staged ONE ELEMENT PER THREAD (4H inputs per step = 4H threads; dropout mask by the
+//     counter hash of that element) — staging 16-byte pieces in wave 0 made that wave the straggler of every barrier;
+//     x_{t+2..t+4} are prefetched in three rotating register slots; the time loop is branch-free (clamped loads, T % 3
+//     steps peeled, slot use pinned with an empty asm) so the compiler emits one counted s_waitcnt vmcnt per step;
+//   * the input projection W_ih x_{t+1} is formed during step t, its MFMAs hand-interleaved with the cell update's vector
+//     instructions (sched_barrier-pinned): it does not depend on h_t, and both waves of a SIMD are in phase, so without the
+//     interleave the matrix pipe idles through every cell update.
+// Ablation of one layer-1 step (round 1): recurrent MFMAs 21 %, input MFMAs 10 %, accumulator re-deal through LDS 16 %
+// (-> DPP), input staging + dropout hashing in wave 0 9 % (-> per thread), cell update + barrier + LDS operand round trip 45 %.
 //
 // Layer pipelining (lstm_fwd_pair_bf16_kernel): a 2-layer stack runs as ONE launch of 2 x tiles workgroups.  Layer 1 of
 // tile i consumes h^0_t of tile i a few steps behind the layer-0 workgroup that produces it, so both layers' recurrences
