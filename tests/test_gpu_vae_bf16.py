@@ -179,7 +179,7 @@ def test_bf16_layer_pipelined_launch_is_bit_identical(train_mode):
 
 
 @pytest.mark.parametrize("shape", [(1, 1, 128), (3, 2, 128), (5, 3, 64), (2, 5, 32), (4, 7, 128), (6, 13, 64), (7, 40, 128, 12), (5, 33, 128, 1),
-                                   (6, 30, 64, 12)])
+                                   (6, 30, 64, 12), (9, 1001, 128), (3, 1501, 32)])     # long sequences (reference runs have 1001 samples)
 def test_bf16_matches_fp32_path_at_degenerate_shapes(shape):
     """The fp32 path is pinned to the reference at the golden shapes; here it is the checker for sequence lengths around the
     kernels' pipeline depths (hand-off delay 4, 4-step dx chunks, prefetch depth 3/4) and for single windows."""
