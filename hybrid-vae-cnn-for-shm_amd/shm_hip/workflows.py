@@ -77,6 +77,35 @@ def train_vae(Ztr: np.ndarray, Zva: np.ndarray, out_dir, *, epochs=50, batch_siz
     return vae, hist
 
 
+def train_vae_1dof(Ztr: np.ndarray, out_dir, *, n_epochs=100, batch_size=64, lr=1e-3, latent_dim=5, hidden_dim=32, num_layers=2, dropout=0.2,
+                   anneal_ratio=0.3, seed=0, precision="fp32", device="cuda", log=print):
+    """1_DOF/Scripts/03_train_vae.py:262-335: the 1_DOF trainer differs from the 4DOF one in every knob around the same step — model
+    without LayerNorm, Adam without weight decay, no gradient clipping, 0-based epoch in the KL schedule, the epoch average taken over
+    BATCHES (sum of batch means / number of batches, :316-318), no validation pass, final (not best) weights saved."""
+    from .schedules import kl_weight_1dof
+    out_dir = Path(out_dir); out_dir.mkdir(parents=True, exist_ok=True)
+    torch.manual_seed(seed); np.random.seed(seed)
+    vae = _vae_class()(Ztr.shape[2], latent_dim, hidden_dim, num_layers, dropout, layer_norm=False, precision=precision).to(device)
+    tr = VAETrainer(vae, lr=lr, weight_decay=0.0, max_norm=None, seed=seed)
+    xtr = torch.from_numpy(Ztr).to(device)
+    hist = {k: [] for k in ("epoch", "loss_total", "loss_recon", "loss_kl", "kl_weight")}
+    for epoch in range(n_epochs):
+        w = kl_weight_1dof(epoch, n_epochs, anneal_ratio)
+        vae.train()
+        perm = torch.randperm(xtr.size(0)).to(device)                 # DataLoader(shuffle=True) on the global torch RNG
+        sums, nb = np.zeros(3), 0
+        for i in range(0, xtr.size(0), batch_size):
+            s = tr.step(xtr.index_select(0, perm[i:i + batch_size]), w).cpu().numpy()
+            sums += s[:3]; nb += 1
+        avg = sums / max(nb, 1)
+        for k, v in zip(("loss_total", "loss_recon", "loss_kl"), avg): hist[k].append(float(v))
+        hist["epoch"].append(epoch + 1); hist["kl_weight"].append(float(w))
+        if (epoch + 1) % 10 == 0:
+            log(f"[epoch {epoch + 1:3d}/{n_epochs}] loss={avg[0]:.6f} recon={avg[1]:.6f} kl={avg[2]:.6f} w={w:.3f}")
+    torch.save(vae.state_dict(), out_dir / "temporal_vae_state_dict.pt")
+    return vae, hist
+
+
 def vae_threshold(vae, Z_normal_val: np.ndarray, out_dir, *, percentile=99.0, batch=512, device="cuda", extra=None):
     """04_vae_thresholding.py:113-124,283,293-311: threshold = P99 of the normal-validation per-window MSE."""
     scores = score_windows(vae, torch.from_numpy(Z_normal_val).to(device), batch).cpu().numpy()

@@ -137,3 +137,26 @@ def test_device_windowing_is_bit_identical_to_host_prep():
     assert dataprep.device_windows(dev, [], T, mean, std).shape == (0, T, D)
     with pytest.raises(ValueError):
         dataprep.device_windows(dev, [700 - T + 1], T)
+
+
+def test_train_vae_1dof_loop_semantics(tmp_path):
+    """1_DOF trainer (1_DOF/Scripts/03_train_vae.py:262-335): no LayerNorm, no weight decay, no clipping, 0-based KL epoch, batch-mean
+    epoch averages, final weights saved; and the 1_DOF evaluation helpers on its reconstruction."""
+    from shm_hip import dataprep, workflows
+    from shm_hip.schedules import kl_weight_1dof
+    rng = np.random.default_rng(2)
+    t = np.arange(400)[:, None] * 0.05
+    series = (np.sin(t * np.linspace(0.5, 1.5, 12)[None, :]) + 0.05 * rng.standard_normal((400, 12))).astype(np.float32)
+    W = dataprep.make_windows(series, 80, 1)
+    logs = []
+    vae, hist = workflows.train_vae_1dof(W, tmp_path, n_epochs=10, batch_size=64, log=logs.append)
+    assert "layer_norm.weight" not in vae.state_dict() and (tmp_path / "temporal_vae_state_dict.pt").exists()
+    assert hist["kl_weight"] == [pytest.approx(kl_weight_1dof(e, 10, 0.3)) for e in range(10)] and len(logs) == 1
+    assert hist["loss_recon"][-1] < hist["loss_recon"][0]
+    # stitched reconstruction of the overlapping windows and its per-segment RMSE (datasets.py:38-71)
+    vae.eval()
+    with torch.no_grad():
+        rec, _, _ = vae(torch.from_numpy(W).cuda())
+    stitched = dataprep.stitch_windows(rec.cpu().numpy(), series.shape[0], 1)
+    rm = dataprep.segment_rmse(series, stitched, 100)
+    assert stitched.shape == series.shape and rm.shape == (4,) and np.isfinite(rm).all()
