@@ -194,6 +194,33 @@ size_t  shm_olcnn_workspace_bytes(const shm_olcnn_config* cfg, int32_t B);
 int     shm_olcnn_forward(const shm_olcnn_config* cfg, const float* params, const float* x, float* logits, int32_t B,
                           void* workspace, void* stream);
 
+/* ---- synthetic data generators on the device --------------------------------------------------------------
+ * All buffers are device memory owned by the caller; calls are asynchronous on `stream`.
+ *
+ * shm_sim_smooth_force: the smoothing half of init_force (4DOF/Scripts/utils/simulation_4dof.py:31-42): base [R][steps][nd] fp64 (the
+ * caller's Gaussian draw x rms) -> force [R][steps][nd] fp32 = centred rolling mean over `window` rows with min_periods = 1
+ * (rows t - window/2 .. t + (window-1)/2 that exist); the reference uses window = max(1, int(0.5 / dt)).
+ *
+ * shm_sim_newmark: run_simulation (simulation_4dof.py:80-137) for R independent runs, zero initial displacement / velocity.
+ * sys [R][nd + 2 nd^2] fp64 per run = { masses | damping matrix C row-major | inverse of (a0 M + a1 C + K) row-major } with
+ * a0 = 1/(beta dt^2), a1 = gamma/(beta dt) — the host side forms them (compute_matrices, :45-77, is an nd x nd eigenproblem per run).
+ * force fp32 [R][steps][nd], or [steps][nd] shared by every run if shared_force != 0 (the structural-fault cases,
+ * 02_generate_fault_datasets.py:152-170).  out [R][steps][3 nd] = x_1..x_nd, v_1..v_nd, a_1..a_nd per step (the reference's
+ * DataFrame columns), fp64, or fp32 if out_f32 != 0; states are clipped to +-1e5 as in :131-133.  nd 1..6.
+ *
+ * shm_sim_sensor_fault: generate_sensor_faults (02_generate_fault_datasets.py:128-149,190-213) in place on table [R][steps][3 nd]
+ * (fp32 if is_f32 != 0, else fp64): columns x_dof, v_dof, a_dof (dof 1-based) of every run get
+ *   kind 0 noise  + mag * z[r][j][t]                      (z standard normal, [R][3][nz = steps])
+ *   kind 1 spikes + mag + mag/4 * z[r][j][s] at row idx[r][j][s]   ([R][3][nz], positions distinct per column)
+ *   kind 2 drift  + linspace(0, mag, steps)[t]
+ *   kind 3 bias   + mag
+ * with mag = rel_mag * sample standard deviation (ddof 1) of the uncorrupted column (1.0 if that is 0). */
+int shm_sim_smooth_force(const double* base, int32_t R, int32_t steps, int32_t nd, int32_t window, float* force, void* stream);
+int shm_sim_newmark(const double* sys, const float* force, int32_t shared_force, int32_t R, int32_t steps, int32_t nd,
+                    double dt, double beta, double gamma, void* out, int32_t out_f32, void* stream);
+int shm_sim_sensor_fault(void* table, int32_t is_f32, int32_t R, int32_t steps, int32_t nd, int32_t kind, int32_t dof,
+                         double rel_mag, const double* z, const int32_t* idx, int32_t nz, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

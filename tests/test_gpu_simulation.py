@@ -1,0 +1,178 @@
+"""Device data generators (csrc/simulate.hip behind shm_hip/simulate.py) against the goldens made by the
+reference's own functions and against the numpy oracle.  Tolerances: the excitation is fp32 (1 ulp of slack for a mean that lands
+on a rounding boundary); responses are fp64 recurrences over 1000 steps, held to 1e-9 of each block's amplitude; the fp32 output is
+the fp64 result rounded once; fault injections are elementwise fp64 (1e-12 relative)."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import simulation_oracle as so
+
+pytestmark = pytest.mark.gpu
+G = np.load(Path(__file__).parent / "golden" / "simulation_4dof.npz")
+DT = 0.01
+
+
+def _cfg(tag):
+    from shm_hip import simulate as sim
+    c = sim.default_system_config()
+    c.mass, c.stiffness, c.damping_ratio = G["mass_" + tag].tolist(), G["stiff_" + tag].tolist(), float(G["zeta_" + tag])
+    return c
+
+
+def _blocks_close(got, want, rel):
+    for b in range(3):
+        w = want[..., 4 * b:4 * b + 4]
+        np.testing.assert_allclose(got[..., 4 * b:4 * b + 4], w, rtol=0, atol=rel * np.abs(w).max())
+
+
+def test_host_matrices_match_reference():
+    from shm_hip import simulate as sim
+    tags = ["normal", "jitter", "stiff60"]
+    m, C, K = sim.chain_matrices([G["mass_" + t] for t in tags], [G["stiff_" + t] for t in tags], [float(G["zeta_" + t]) for t in tags])
+    for i, t in enumerate(tags):
+        np.testing.assert_allclose(np.diag(m[i]), G["M_" + t], rtol=0, atol=0)
+        np.testing.assert_allclose(K[i], G["K_" + t], rtol=1e-15)
+        np.testing.assert_allclose(C[i], G["C_" + t], rtol=1e-10)
+
+
+@pytest.mark.parametrize("tag", ["normal", "jitter", "fault"])
+def test_force_smoothing_matches_reference(tag):
+    from shm_hip import simulate as sim
+    base = torch.from_numpy(G["base_" + tag]).cuda()
+    got = sim.init_force(10.0, DT, 4, 0.0, 0, base=base).cpu().numpy()
+    want = G["force_" + tag]
+    assert got.dtype == np.float32 and got.shape == want.shape
+    np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-6 * np.abs(want).max())
+    # batched + odd window + window longer than the series, against the oracle
+    b3 = np.stack([G["base_normal"][:37], G["base_jitter"][:37], G["base_fault"][:37]])
+    for w in (1, 7, 50, 100):
+        g = sim.smooth_force(torch.from_numpy(b3).cuda(), w).cpu().numpy()
+        for r in range(3):
+            np.testing.assert_allclose(g[r], so.smooth_force(b3[r], w), rtol=2e-6, atol=1e-6 * np.abs(b3).max())
+
+
+def test_newmark_matches_reference_batched():
+    """Three systems with their own excitations in ONE launch (fp64 out), then the shared-excitation structural-fault case."""
+    from shm_hip import simulate as sim
+    tags = ["normal", "jitter", "fault"]
+    force = torch.from_numpy(np.stack([G["force_" + t] for t in tags])).cuda()
+    got = sim.run_simulation([_cfg(t) for t in tags], force, dtype=torch.float64).cpu().numpy()
+    for i, t in enumerate(tags):
+        _blocks_close(got[i], G["resp_" + t], 1e-9)
+    shared = torch.from_numpy(G["force_fault"]).cuda()
+    got = sim.run_simulation([_cfg("fault"), _cfg("stiff60")], shared, dtype=torch.float64).cpu().numpy()
+    _blocks_close(got[0], G["resp_fault"], 1e-9)
+    _blocks_close(got[1], G["resp_stiff60"], 1e-9)
+    one = sim.run_simulation(_cfg("stiff60"), shared, dtype=torch.float32)
+    assert one.shape == (1001, 12) and one.dtype == torch.float32
+    _blocks_close(one.cpu().numpy(), G["resp_stiff60"].astype(np.float32), 2e-7)
+    st = sim.structural_faults(_cfg("fault"), shared, dtype=torch.float64)
+    assert list(st) == ["stiff_red_9pct", "stiff_red_19pct", "stiff_red_30pct", "stiff_red_40pct"]     # int((1 - perc) * 100) as the reference
+    _blocks_close(st["stiff_red_40pct"].cpu().numpy(), G["resp_stiff60"], 1e-9)
+
+
+@pytest.mark.parametrize("R,steps,nd", [(1, 1, 4), (3, 9, 4), (70, 33, 4), (130, 17, 2), (5, 40, 6), (2, 25, 1), (66, 21, 5)])
+def test_newmark_shapes_against_oracle(R, steps, nd):
+    """Ragged run counts (partial last wave), step counts that are not a multiple of the staging chunk, other DOF counts."""
+    from shm_hip import simulate as sim
+    rng = np.random.default_rng(100 * R + steps + nd)
+    cfgs = []
+    for _ in range(R):
+        cfgs.append(sim.SystemConfig(mass=rng.uniform(30, 70, nd).tolist(), stiffness=rng.uniform(1e5, 3e5, nd).tolist(),
+                                     damping_ratio=float(rng.uniform(0.01, 0.05)), num_dofs=nd, dt=0.01, T_total=(steps - 1) * 0.01 + 1e-9))
+    assert cfgs[0].steps == steps
+    force = rng.standard_normal((R, steps, nd)).astype(np.float32) * 40
+    if nd == 1:          # the reference's chain needs two springs; the kernel itself is generic: hand it a 1-DOF system directly
+        sys = np.array([[c.mass[0], 2.0, 1.0 / (4e4 * c.mass[0] + 200 * 2.0 + c.stiffness[0])] for c in cfgs])
+        import ctypes as C
+        from shm_hip._capi import check, lib
+        out = torch.empty(R, steps, 3, dtype=torch.float64, device="cuda")
+        sd, fd = torch.from_numpy(sys).cuda(), torch.from_numpy(force).cuda()
+        check(lib.shm_sim_newmark(C.c_void_p(sd.data_ptr()), C.c_void_p(fd.data_ptr()), 0, R, steps, 1, C.c_double(0.01), C.c_double(0.25),
+                                  C.c_double(0.5), C.c_void_p(out.data_ptr()), 0, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "newmark")
+        got = out.cpu().numpy()
+        for r, c in enumerate(cfgs):
+            want = so.newmark(np.array([[c.mass[0]]]), np.array([[2.0]]), np.array([[c.stiffness[0]]]), force[r], 0.01)
+            np.testing.assert_allclose(got[r], want, rtol=0, atol=1e-10 * max(np.abs(want).max(), 1e-30))
+        return
+    got = sim.run_simulation(cfgs, torch.from_numpy(force).cuda(), dtype=torch.float64).cpu().numpy()
+    for r, c in enumerate(cfgs):
+        M, Cm, K = so.system_matrices(c.mass, c.stiffness, c.damping_ratio)
+        want = so.newmark(M, Cm, K, force[r], 0.01)
+        for b in range(3):
+            w = want[:, nd * b:nd * b + nd]
+            np.testing.assert_allclose(got[r][:, nd * b:nd * b + nd], w, rtol=0, atol=1e-9 * max(np.abs(w).max(), 1e-30))
+
+
+def test_newmark_clips_and_survives_nan_force():
+    """States are clipped to +-1e5 and fed back clipped (simulation_4dof.py:131-133); a NaN in F_0 gives a_0 = 0 (nan_to_num)."""
+    from shm_hip import simulate as sim
+    c = sim.SystemConfig(mass=[1e-6, 1e-6], stiffness=[1.0, 1.0], damping_ratio=0.0, num_dofs=2, dt=0.01, T_total=0.2)
+    force = np.full((c.steps, 2), 1e9, dtype=np.float32)
+    force[0, 1] = np.nan
+    got = sim.run_simulation(c, torch.from_numpy(force).cuda(), dtype=torch.float64).cpu().numpy()
+    M, Cm, K = so.system_matrices(c.mass, c.stiffness, c.damping_ratio)
+    want = so.newmark(M, Cm, K, force, c.dt)
+    assert np.abs(want).max() == 1e5 and want[0, 5] == 0.0
+    np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("name", ["noise", "spikes", "drift", "bias"])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_sensor_faults_match_reference(name, dtype):
+    from shm_hip import simulate as sim
+    dof, rel = G[f"sf_{name}_spec"]
+    dof = int(dof)
+    z = torch.from_numpy(G[f"sf_{name}_z"]).cuda().unsqueeze(0) if f"sf_{name}_z" in G.files else None
+    idx = torch.from_numpy(G[f"sf_{name}_idx"]).cuda().unsqueeze(0) if f"sf_{name}_idx" in G.files else None
+    base = torch.from_numpy(G["resp_fault"]).to(dtype).cuda()
+    got = sim.inject_sensor_fault(base, name, dof, float(rel), z=z, idx=idx)
+    assert got.dtype == dtype and got.data_ptr() != base.data_ptr()
+    cols = [dof - 1, dof + 3, dof + 7]
+    others = [c for c in range(12) if c not in cols]
+    assert torch.equal(got[:, others], base[:, others])
+    if dtype == torch.float64:
+        want = G[f"sf_{name}_cols"]
+        np.testing.assert_allclose(got[:, cols].cpu().numpy(), want, rtol=1e-12, atol=1e-12 * np.abs(want).max())
+    else:                # fp32 tables: the oracle on the fp32-rounded table, result rounded to fp32
+        want = so.inject(base.cpu().numpy().astype(np.float64), sim._KINDS[name], dof, float(rel), z=None if z is None else z[0].cpu().numpy(),
+                         idx=None if idx is None else idx[0].cpu().numpy())[:, cols].astype(np.float32)
+        np.testing.assert_allclose(got[:, cols].cpu().numpy(), want, rtol=2e-7, atol=1e-7 * np.abs(want).max())
+
+
+def test_generators_end_to_end(tmp_path):
+    """normal_runs / fault_datasets produce tables the data prep can window on the device; statistics are in the reference's range."""
+    from shm_hip import dataprep, simulate as sim
+    tables, cfgs = sim.normal_runs(n_runs=10, jitter_seed=3)
+    assert tables.shape == (10, 1001, 12) and tables.dtype == torch.float32 and len(cfgs) == 10
+    assert torch.isfinite(tables).all()
+    amp = tables[:, :, :4].abs().amax().item()
+    assert 1e-4 < amp < 5e-3                       # the reference's normal runs peak at ~6e-4 m (golden "normal": 6.3e-4)
+    # every run equals a single-run call with its own config and excitation
+    force = sim.init_force(10.0, 0.01, 4, 50.0, 2025, n_runs=10)
+    one = sim.run_simulation(cfgs[7], force[7])
+    assert torch.equal(one, tables[7])
+    normal, structural, sensor = sim.fault_datasets(seed=5)
+    assert set(sensor) == {"noise_x4", "spikes_x1", "drift_x2", "bias_x3"} and len(structural) == 4
+    assert (sensor["bias_x3"][:, 2] - normal[:, 2]).std().item() < 1e-9 and (sensor["bias_x3"][:, 2] - normal[:, 2]).mean().item() > 0
+    changed = (sensor["spikes_x1"][:, 0] != normal[:, 0]).sum().item()
+    assert changed == 10                           # int(1001 * 0.01) distinct rows
+    p = sim.save_csv(structural["stiff_red_40pct"], tmp_path / "s.csv")
+    back = dataprep.load_csv_numeric(p, 12)
+    np.testing.assert_allclose(back, structural["stiff_red_40pct"].cpu().numpy(), rtol=1e-6)
+    W = dataprep.device_windows(normal[:, :4].contiguous(), np.arange(0, 1001 - 256 + 1, 64), 256)
+    assert W.shape == (12, 256, 4)
+
+
+def test_argument_errors():
+    from shm_hip import simulate as sim
+    with pytest.raises(RuntimeError):
+        sim.smooth_force(torch.zeros(5, 4, dtype=torch.float64), 3)                      # CPU tensor: no CPU path
+    c = sim.default_system_config()
+    with pytest.raises(ValueError):
+        sim.run_simulation(c, torch.zeros(7, 4, device="cuda"))                          # wrong step count
+    with pytest.raises(RuntimeError):
+        sim.inject_sensor_fault(torch.zeros(10, 12, device="cuda"), "bias", 5, 1.0)      # dof outside 1..4
