@@ -6,8 +6,8 @@
 //
 // The recurrence is sequential in time and only nd x nd wide, so the parallel axis is the RUN: one thread integrates one run in fp64
 // with its system matrices in registers; a workgroup is one wave of 64 runs.  Per step a thread produces 3 nd values of ITS run —
-// written directly that would be a 64-way scatter — so 8 steps (4 for nd > 4) are staged in LDS as [run][8 x 3 nd] and the wave then copies every
-// run's 8-step block (768 B in fp32 at nd = 4) out with consecutive lanes on consecutive addresses.  HBM-bound on the response table
+// written directly that would be a 64-way scatter — so 8 steps (4 for fp64 tables) are staged in LDS as [run][8 x 3 nd] and the wave then copies every
+// run's 8-step block (768 B in fp32 at nd = 4) out with consecutive lanes on consecutive 16-byte pieces.  HBM-bound on the response table
 // for large run counts (48 KB per run in fp32); latency-bound (1000 dependent steps) for a handful of runs.
 // Compiled with -ffp-contract=off like the rest of the library, so products and sums round the way the numpy restatement does.
 #include <math.h>
@@ -19,29 +19,38 @@ namespace shm {
 namespace {
 
 constexpr int SIM_RUNS = 64;        // runs per workgroup (one wave)
-constexpr int sim_chunk(int nd) { return nd <= 4 ? 8 : 4; }      // steps staged in LDS between copy-outs (<= 64 KB of LDS)
+constexpr int sim_chunk(size_t elem) { return elem == 4 ? 8 : 4; }      // steps staged in LDS between copy-outs (<= 37 KB: >= 4 waves per CU)
 constexpr double SIM_CLIP = 1e5;
 
 __device__ __forceinline__ double clip5(double v) { return fmin(fmax(v, -SIM_CLIP), SIM_CLIP); }   // np.clip: NaN stays NaN
 __device__ __forceinline__ void put(float* p, double v) { *p = (float)v; }
 __device__ __forceinline__ void put(double* p, double v) { *p = v; }
 
-// force[r][t][d] = fp32( mean over the existing rows of base[r][t - w/2 .. t + (w-1)/2][d] )
-__global__ void __launch_bounds__(256) force_smooth_kernel(const double* __restrict__ base, int R, int steps, int nd, int window,
+// force[r][t][d] = fp32( mean over the existing rows of base[r][t - w/2 .. t + (w-1)/2][d] ), summed first row to last in fp64.
+// One workgroup per (run, 128-step segment): the segment's rows plus the window halo go through LDS once (each base value is
+// needed by `window` outputs), then every thread sums its window out of LDS — consecutive threads on consecutive (t, d).
+constexpr int SMOOTH_SEG = 128;
+__global__ void __launch_bounds__(256) force_smooth_kernel(const double* __restrict__ base, int steps, int nd, int window,
                                                            float* __restrict__ force) {
-    const size_t total = (size_t)R * steps * nd;
+    extern __shared__ double tile[];                 // [(SMOOTH_SEG + window - 1)][nd]
     const int back = window / 2, fwd = (window - 1) / 2;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int d = (int)(i % nd);
-        const size_t rt = i / nd;
-        const int t = (int)(rt % steps);
-        const size_t r = rt / steps;
+    const int t0 = blockIdx.y * SMOOTH_SEG, r = blockIdx.x;
+    const int nseg = min(SMOOTH_SEG, steps - t0);
+    const int row0 = t0 - back;                      // table row of tile row 0 (may be negative)
+    const int nrows = nseg + back + fwd;
+    const double* b = base + (size_t)r * steps * nd;
+    for (int e = threadIdx.x; e < nrows * nd; e += 256) {
+        const int row = row0 + e / nd;
+        tile[e] = (row >= 0 && row < steps) ? b[(size_t)row * nd + (e % nd)] : 0.0;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < nseg * nd; e += 256) {
+        const int t = t0 + e / nd, d = e % nd;
         const int lo = t - back < 0 ? 0 : t - back;
         const int hi = t + fwd >= steps ? steps - 1 : t + fwd;
-        const double* col = base + (r * steps) * nd + d;
         double s = 0.0;
-        for (int u = lo; u <= hi; ++u) s += col[(size_t)u * nd];
-        force[i] = (float)(s / (double)(hi - lo + 1));
+        for (int u = lo; u <= hi; ++u) s += tile[(u - row0) * nd + d];
+        force[((size_t)r * steps + t) * nd + d] = (float)(s / (double)(hi - lo + 1));
     }
 }
 
@@ -54,9 +63,11 @@ __global__ void __launch_bounds__(SIM_RUNS) newmark_kernel(const double* __restr
                                                            long long force_stride, int R, int steps, NewmarkCoef k,
                                                            TO* __restrict__ out) {
     constexpr int NV = 3 * ND;                       // values per step
-    constexpr int SIM_CH = sim_chunk(ND);
-    constexpr int ROW = SIM_CH * NV + 1;             // +1: lanes step through LDS with an odd stride (conflict-free staging writes)
-    __shared__ double stage[SIM_RUNS * ROW];
+    constexpr int SIM_CH = sim_chunk(sizeof(TO));    // steps staged between copy-outs
+    constexpr int PER = SIM_CH * NV;                 // values of one run in a full chunk: contiguous in the table
+    constexpr int ROW = PER + 1;                     // +1: lanes step through LDS with an odd stride (conflict-free staging writes)
+    constexpr int VW = (NV * sizeof(TO)) % 16 == 0 ? 16 / sizeof(TO) : 1;      // values per 16-byte store when every step row is 16-B aligned
+    __shared__ TO stage[SIM_RUNS * ROW];             // staged in the output type: fp32 tables are rounded once, here
     const int lane = threadIdx.x;
     const int r = blockIdx.x * SIM_RUNS + lane;
     const int rr = r < R ? r : R - 1;                // idle lanes of the last workgroup shadow the last run and store nothing
@@ -83,97 +94,154 @@ __global__ void __launch_bounds__(SIM_RUNS) newmark_kernel(const double* __restr
         for (int j = 0; j < ND; ++j) a0 += (j == i ? 1.0 / m[i] : 0.0) * (double)f[j];
         a[i] = a0 != a0 ? 0.0 : fmin(fmax(a0, -1.7976931348623157e308), 1.7976931348623157e308);
     }
-    double* mine = stage + lane * ROW;
+    TO* mine = stage + lane * ROW;
     const int wg_runs = min(SIM_RUNS, R - blockIdx.x * SIM_RUNS);
     TO* out_wg = out + (size_t)blockIdx.x * SIM_RUNS * steps * NV;
 
-    for (int t0 = 0; t0 < steps; t0 += SIM_CH) {
-        const int nst = min(SIM_CH, steps - t0);
-        for (int u = 0; u < nst; ++u) {
-            const int t = t0 + u;
-            if (t > 0) {
-                double p[ND], q[ND], rhs[ND], xn[ND];
+    auto advance = [&](int t) {
+        double p[ND], q[ND], rhs[ND], xn[ND];
 #pragma unroll
-                for (int i = 0; i < ND; ++i) {
-                    p[i] = k.c0 * x[i] + k.c2 * v[i] + k.c3 * a[i];
-                    q[i] = k.c1 * x[i] + k.c4 * v[i] + k.c5 * a[i];
-                }
+        for (int i = 0; i < ND; ++i) {
+            p[i] = k.c0 * x[i] + k.c2 * v[i] + k.c3 * a[i];
+            q[i] = k.c1 * x[i] + k.c4 * v[i] + k.c5 * a[i];
+        }
 #pragma unroll
-                for (int i = 0; i < ND; ++i) {
-                    double cq = 0.0;
+        for (int i = 0; i < ND; ++i) {
+            double cq = 0.0;
 #pragma unroll
-                    for (int j = 0; j < ND; ++j) cq += C[i][j] * q[j];
-                    rhs[i] = (double)f[(size_t)t * ND + i] + m[i] * p[i] + cq;
-                }
+            for (int j = 0; j < ND; ++j) cq += C[i][j] * q[j];
+            rhs[i] = (double)f[(size_t)t * ND + i] + m[i] * p[i] + cq;
+        }
 #pragma unroll
-                for (int i = 0; i < ND; ++i) {
-                    double s = 0.0;
+        for (int i = 0; i < ND; ++i) {
+            double s = 0.0;
 #pragma unroll
-                    for (int j = 0; j < ND; ++j) s += Ki[i][j] * rhs[j];
-                    xn[i] = s;
-                }
+            for (int j = 0; j < ND; ++j) s += Ki[i][j] * rhs[j];
+            xn[i] = s;
+        }
 #pragma unroll
-                for (int i = 0; i < ND; ++i) {
-                    const double an = k.c0 * (xn[i] - x[i]) - k.c2 * v[i] - k.c3 * a[i];
-                    const double vn = v[i] + k.dt * ((1.0 - k.gamma) * a[i] + k.gamma * an);
-                    x[i] = clip5(xn[i]); v[i] = clip5(vn); a[i] = clip5(an);       // the clipped state is what the next step sees
-                }
-            }
+        for (int i = 0; i < ND; ++i) {
+            const double an = k.c0 * (xn[i] - x[i]) - k.c2 * v[i] - k.c3 * a[i];
+            const double vn = v[i] + k.dt * ((1.0 - k.gamma) * a[i] + k.gamma * an);
+            x[i] = clip5(xn[i]); v[i] = clip5(vn); a[i] = clip5(an);       // the clipped state is what the next step sees
+        }
+    };
+    auto stash = [&](int u) {
 #pragma unroll
-            for (int i = 0; i < ND; ++i) { mine[u * NV + i] = x[i]; mine[u * NV + ND + i] = v[i]; mine[u * NV + 2 * ND + i] = a[i]; }
+        for (int i = 0; i < ND; ++i) { mine[u * NV + i] = (TO)x[i]; mine[u * NV + ND + i] = (TO)v[i]; mine[u * NV + 2 * ND + i] = (TO)a[i]; }
+    };
+
+    int t0 = 0;
+    for (; t0 + SIM_CH <= steps; t0 += SIM_CH) {     // full chunks: compile-time extents, 16-byte stores
+#pragma unroll
+        for (int u = 0; u < SIM_CH; ++u) {
+            if (t0 + u > 0) advance(t0 + u);
+            stash(u);
         }
         __syncthreads();                             // one wave per workgroup: orders the LDS writes before the cross-lane reads
-        // copy-out: run q's block of nst*NV values is contiguous in the table at out[q][t0][0]
-        const int per = nst * NV;
-        for (int i = lane; i < wg_runs * per; i += SIM_RUNS) {
-            const int q = i / per, e = i - q * per;
-            put(out_wg + ((size_t)q * steps + t0) * NV + e, stage[q * ROW + e]);
+        // copy-out: run q's PER values are contiguous in the table at out[q][t0][0]; consecutive lanes take consecutive 16-byte pieces
+        constexpr int NVEC = PER / VW;
+        for (int i = lane; i < wg_runs * NVEC; i += SIM_RUNS) {
+            const int q = i / NVEC, e = (i - q * NVEC) * VW;
+            typedef TO vec_t __attribute__((ext_vector_type(VW)));
+            vec_t val;
+            if constexpr (VW == 1) val = stage[q * ROW + e];
+            else {
+#pragma unroll
+                for (int w = 0; w < VW; ++w) val[w] = stage[q * ROW + e + w];
+            }
+            *reinterpret_cast<vec_t*>(out_wg + ((size_t)q * steps + t0) * NV + e) = val;
         }
         __syncthreads();
     }
+    if (t0 < steps) {                                // ragged tail
+        const int nst = steps - t0;
+        for (int u = 0; u < nst; ++u) {
+            if (t0 + u > 0) advance(t0 + u);
+            stash(u);
+        }
+        __syncthreads();
+        const int per = nst * NV;
+        for (int i = lane; i < wg_runs * per; i += SIM_RUNS) {
+            const int q = i / per, e = i - q * per;
+            out_wg[((size_t)q * steps + t0) * NV + e] = stage[q * ROW + e];
+        }
+    }
 }
 
-// One workgroup per (run, j): column (dof-1) + j*nd of the run's table gets the fault.  kind: 0 noise, 1 spikes, 2 drift, 3 bias.
+// One workgroup per run: sample standard deviation of the three columns x_dof, v_dof, a_dof (two passes, fp64), then ONE pass that
+// copies the run's table src -> dst (src may equal dst) with the fault added to those columns.  kind: 0 noise, 1 spikes, 2 drift, 3 bias.
 template <typename T>
-__global__ void __launch_bounds__(256) sensor_fault_kernel(T* __restrict__ table, int steps, int ncols, int nd, int kind, int dof,
-                                                           double rel_mag, const double* __restrict__ z, const int* __restrict__ idx,
-                                                           int nz) {
-    __shared__ double red[256];
-    const int r = blockIdx.x, j = blockIdx.y, tid = threadIdx.x;
-    T* col = table + (size_t)r * steps * ncols + (dof - 1) + j * nd;
-    auto block_sum = [&](double v) {
-        red[tid] = v;
+__global__ void __launch_bounds__(256) sensor_fault_kernel(const T* src, T* dst, int steps, int nd, int kind,
+                                                           int dof, double rel_mag, const double* __restrict__ z,
+                                                           const int* __restrict__ idx, int nz) {
+    __shared__ double red[3][256];
+    const int r = blockIdx.x, tid = threadIdx.x, ncols = 3 * nd, c0 = dof - 1;
+    const T* in = src + (size_t)r * steps * ncols;
+    T* out = dst + (size_t)r * steps * ncols;
+    const bool inplace = (const T*)dst == src;
+    double acc[3], mean[3], mag[3];
+    auto block_sum3 = [&]() {                        // acc[] -> block totals in acc[], same fixed order for every thread
+#pragma unroll
+        for (int j = 0; j < 3; ++j) red[j][tid] = acc[j];
         __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
-        const double tot = red[0];
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) red[j][tid] += red[j][tid + s];
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[j] = red[j][0];
         __syncthreads();
-        return tot;
     };
-    double acc = 0.0;
-    for (int t = tid; t < steps; t += 256) acc += (double)col[(size_t)t * ncols];
-    const double mean = block_sum(acc) / (double)steps;
-    acc = 0.0;
-    for (int t = tid; t < steps; t += 256) { const double dv = (double)col[(size_t)t * ncols] - mean; acc += dv * dv; }
-    const double ssq = block_sum(acc);
-    const double sd = steps > 1 ? sqrt(ssq / (double)(steps - 1)) : NAN;           // pandas .std(): ddof = 1
-    const double mag = (sd > 0.0 ? sd : 1.0) * rel_mag;                            // NaN > 0 is false, as in the reference
-    const double* zz = z ? z + ((size_t)r * 3 + j) * nz : nullptr;
-    if (kind == 0) {
-        for (int t = tid; t < steps; t += 256) put(col + (size_t)t * ncols, (double)col[(size_t)t * ncols] + mag * zz[t]);
-    } else if (kind == 1) {
-        const int* ii = idx + ((size_t)r * 3 + j) * nz;
-        for (int s = tid; s < nz; s += 256) {
-            const int t = ii[s];
-            if (t >= 0 && t < steps) put(col + (size_t)t * ncols, (double)col[(size_t)t * ncols] + (mag + (mag / 4.0) * zz[s]));
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[j] = 0.0;
+    for (int t = tid; t < steps; t += 256) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[j] += (double)in[(size_t)t * ncols + c0 + j * nd];
+    }
+    block_sum3();
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { mean[j] = acc[j] / (double)steps; acc[j] = 0.0; }
+    for (int t = tid; t < steps; t += 256) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { const double dv = (double)in[(size_t)t * ncols + c0 + j * nd] - mean[j]; acc[j] += dv * dv; }
+    }
+    block_sum3();
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double sd = steps > 1 ? sqrt(acc[j] / (double)(steps - 1)) : NAN;    // pandas .std(): ddof = 1
+        mag[j] = (sd > 0.0 ? sd : 1.0) * rel_mag;                                  // NaN > 0 is false, as in the reference
+    }
+    const double* zr = z ? z + (size_t)r * 3 * nz : nullptr;
+    const int total = steps * ncols;
+    for (int i = tid; i < total; i += 256) {
+        const int t = i / ncols, c = i - t * ncols;
+        const int jj = c - c0;
+        const T val = in[i];
+        if (jj >= 0 && jj % nd == 0 && kind != 1) {
+            const int j = jj / nd;
+            double add;
+            if (kind == 0) add = mag[j] * zr[(size_t)j * nz + t];
+            else if (kind == 2) add = (t == steps - 1 && steps > 1) ? mag[j] : (double)t * (steps > 1 ? mag[j] / (double)(steps - 1) : 0.0);   // np.linspace(0, mag, steps)
+            else add = mag[j];
+            put(out + i, (double)val + add);
+        } else if (!inplace) {
+            out[i] = val;
         }
-    } else if (kind == 2) {
-        const double step = steps > 1 ? mag / (double)(steps - 1) : 0.0;           // np.linspace(0, mag, steps)
-        for (int t = tid; t < steps; t += 256) {
-            const double add = (t == steps - 1 && steps > 1) ? mag : (double)t * step;
-            put(col + (size_t)t * ncols, (double)col[(size_t)t * ncols] + add);
+    }
+    if (kind == 1) {                                 // sparse: after the copy, read-modify-write the spike rows (distinct per column)
+        __syncthreads();
+        const int* ir = idx + (size_t)r * 3 * nz;
+        for (int s = tid; s < 3 * nz; s += 256) {
+            const int j = s / nz, t = ir[s];
+            if (t >= 0 && t < steps) {
+                T* p = out + (size_t)t * ncols + c0 + j * nd;
+                put(p, (double)*p + (mag[j] + (mag[j] / 4.0) * zr[s]));
+            }
         }
-    } else {
-        for (int t = tid; t < steps; t += 256) put(col + (size_t)t * ncols, (double)col[(size_t)t * ncols] + mag);
     }
 }
 
@@ -196,11 +264,13 @@ using namespace shm;
 extern "C" int shm_sim_smooth_force(const double* base, int32_t R, int32_t steps, int32_t nd, int32_t window, float* force, void* stream) {
     SHM_REQUIRE(R >= 0 && steps >= 1 && nd >= 1 && window >= 1, SHM_EINVAL, "sim_smooth_force: bad shape (R=%d steps=%d nd=%d window=%d)",
                 R, steps, nd, window);
+    const size_t lds = (size_t)(SMOOTH_SEG + window - 1) * nd * sizeof(double);
+    SHM_REQUIRE(lds <= 64 * 1024, SHM_EINVAL, "sim_smooth_force: window %d x %d channels exceeds the LDS tile (64 KB)", window, nd);
+    SHM_REQUIRE((steps + SMOOTH_SEG - 1) / SMOOTH_SEG <= 65535, SHM_EINVAL, "sim_smooth_force: steps %d too large", steps);
     if (R == 0) return SHM_OK;
     SHM_REQUIRE(base && force, SHM_EINVAL, "sim_smooth_force: NULL base or force");
-    const size_t total = (size_t)R * steps * nd;
-    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(force_smooth_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, base, R, steps, nd, window, force);
+    hipLaunchKernelGGL(force_smooth_kernel, dim3(R, (steps + SMOOTH_SEG - 1) / SMOOTH_SEG), dim3(256), lds, (hipStream_t)stream,
+                       base, steps, nd, window, force);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
@@ -228,19 +298,21 @@ extern "C" int shm_sim_newmark(const double* sys, const float* force, int32_t sh
     }
 }
 
-extern "C" int shm_sim_sensor_fault(void* table, int32_t is_f32, int32_t R, int32_t steps, int32_t nd, int32_t kind, int32_t dof,
-                                    double rel_mag, const double* z, const int32_t* idx, int32_t nz, void* stream) {
+extern "C" int shm_sim_sensor_fault(const void* src, void* dst, int32_t is_f32, int32_t R, int32_t steps, int32_t nd, int32_t kind,
+                                    int32_t dof, double rel_mag, const double* z, const int32_t* idx, int32_t nz, void* stream) {
     SHM_REQUIRE(R >= 0 && steps >= 1 && nd >= 1, SHM_EINVAL, "sim_sensor_fault: bad shape (R=%d steps=%d nd=%d)", R, steps, nd);
+    SHM_REQUIRE((long long)steps * 3 * nd < (1ll << 31), SHM_EINVAL, "sim_sensor_fault: a run's table exceeds 2^31 values");
     SHM_REQUIRE(kind >= 0 && kind <= 3, SHM_EINVAL, "sim_sensor_fault: kind %d unknown (0 noise, 1 spikes, 2 drift, 3 bias)", kind);
     SHM_REQUIRE(dof >= 1 && dof <= nd, SHM_EINVAL, "sim_sensor_fault: dof %d outside 1..%d", dof, nd);
     if (R == 0) return SHM_OK;
-    SHM_REQUIRE(table, SHM_EINVAL, "sim_sensor_fault: NULL table");
+    SHM_REQUIRE(src && dst, SHM_EINVAL, "sim_sensor_fault: NULL src or dst");
     if (kind == 0) SHM_REQUIRE(z && nz == steps, SHM_EINVAL, "sim_sensor_fault: noise needs z [R][3][steps] (nz=%d, steps=%d)", nz, steps);
     if (kind == 1) SHM_REQUIRE(nz >= 0 && (nz == 0 || (z && idx)), SHM_EINVAL, "sim_sensor_fault: spikes need z and idx [R][3][nz]");
-    const dim3 grid(R, 3), block(256);
+    if (kind != 1 && kind != 0) nz = 0;
+    const dim3 grid(R), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (is_f32) hipLaunchKernelGGL((sensor_fault_kernel<float>), grid, block, 0, s, (float*)table, steps, 3 * nd, nd, kind, dof, rel_mag, z, idx, nz);
-    else        hipLaunchKernelGGL((sensor_fault_kernel<double>), grid, block, 0, s, (double*)table, steps, 3 * nd, nd, kind, dof, rel_mag, z, idx, nz);
+    if (is_f32) hipLaunchKernelGGL((sensor_fault_kernel<float>), grid, block, 0, s, (const float*)src, (float*)dst, steps, nd, kind, dof, rel_mag, z, idx, nz);
+    else        hipLaunchKernelGGL((sensor_fault_kernel<double>), grid, block, 0, s, (const double*)src, (double*)dst, steps, nd, kind, dof, rel_mag, z, idx, nz);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }

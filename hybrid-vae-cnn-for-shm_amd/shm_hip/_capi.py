@@ -58,7 +58,7 @@ def _load():
         "shm_sim_smooth_force": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp]),
         "shm_sim_newmark": (C.c_int, [vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double,
                                       vp, C.c_int32, vp]),
-        "shm_sim_sensor_fault": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double,
+        "shm_sim_sensor_fault": (C.c_int, [vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double,
                                            vp, vp, C.c_int32, vp]),
         "shm_window_gather": (C.c_int, [vp, C.c_int64, C.c_int32, vp, C.c_int32, C.c_int32, vp, vp, C.c_float, vp, vp]),
         "shm_cnn_eval_loss": (C.c_int, [vp, vp, C.c_int32, C.c_int32, vp, vp]),

@@ -141,6 +141,48 @@ def device_windows(series, starts, win_len: int, mean=None, std=None, clip_z: fl
     return out
 
 
+# ---- run_splits.json (reference 4DOF/Scripts/00_make_run_splits.py:15-141): per file, contiguous train / val / test blocks of window indices
+def contiguous_split(n_windows: int, train_frac: float = 0.40, val_frac: float = 0.30):
+    n = max(int(n_windows), 0)
+    n_tr, n_va = int(train_frac * n), int(val_frac * n)
+    return {"train": list(range(n_tr)), "val": list(range(n_tr, n_tr + n_va)), "test": list(range(n_tr + n_va, n))}
+
+
+def make_run_splits(root, seq_len: int = 100, stride: int = 1, train_frac: float = 0.40, val_frac: float = 0.30, seed: int = 42, write: bool = True):
+    """Scans <root>/Data/raw (normal/*.csv, faults/sensor_fault/**, faults/structural_fault/**) and returns — and by default writes to
+    Data/processed/run_splits.json — the split description every stage reads: mode "window_level_per_file", file paths relative to
+    root with forward slashes, window indices 0 .. n_windows-1 cut 40 / 30 / rest per file without shuffling."""
+    import json
+    root = Path(root)
+    out = {"mode": "window_level_per_file", "seed": seed,
+           "fractions": {"train": train_frac, "val": val_frac, "test": round(1.0 - train_frac - val_frac, 10)},
+           "seq_len": seq_len, "stride": stride}
+    totals = {}
+    for key, pattern in (("normal", "Data/raw/normal/*.csv"), ("sensor_fault", "Data/raw/faults/sensor_fault/**/*.csv"),
+                         ("structural_fault", "Data/raw/faults/structural_fault/**/*.csv")):
+        files, widx, tot = [], {}, {"train": 0, "val": 0, "test": 0}
+        for fp in sorted(root.glob(pattern)):
+            with open(fp, "r", encoding="utf-8", errors="ignore") as fh:
+                n_rows = max(sum(1 for _ in fh) - 1, 0)
+            n_win = 0 if n_rows < seq_len else 1 + (n_rows - seq_len) // stride
+            if n_win <= 0:
+                continue
+            rel = fp.relative_to(root).as_posix()
+            files.append(rel)
+            widx[rel] = contiguous_split(n_win, train_frac, val_frac)
+            for k in tot:
+                tot[k] += len(widx[rel][k])
+        out[key] = {"files": files, "window_indices": widx}
+        totals[key] = tot
+    out["totals"] = totals
+    out["note"] = "contiguous time-block split per file (no shuffle)"
+    if write:
+        dst = root / "Data/processed/run_splits.json"
+        dst.parent.mkdir(parents=True, exist_ok=True)
+        dst.write_text(json.dumps(out, indent=2), encoding="utf-8")
+    return out
+
+
 # ---- 1_DOF evaluation helpers (1_DOF/Scripts/datasets.py:38-71)
 def stitch_windows(windows: np.ndarray, full_len: int, stride: int = 1) -> np.ndarray:
     """Average the overlapping sliding-window reconstructions back into one series [full_len, F] (fp64, as the reference)."""

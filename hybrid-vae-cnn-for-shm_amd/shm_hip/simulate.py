@@ -195,7 +195,7 @@ def inject_sensor_fault(table: torch.Tensor, kind, dof: int, rel_mag: float, z: 
     _need_cuda(table, "inject_sensor_fault: table")
     k = _KINDS[kind] if isinstance(kind, str) else int(kind)
     squeeze = table.dim() == 2
-    t = (table.unsqueeze(0) if squeeze else table).contiguous().clone()
+    t = (table.unsqueeze(0) if squeeze else table).contiguous()
     if t.dtype not in (torch.float32, torch.float64):
         raise ValueError("inject_sensor_fault: table must be fp32 or fp64")
     R, steps, ncols = t.shape
@@ -215,10 +215,11 @@ def inject_sensor_fault(table: torch.Tensor, kind, dof: int, rel_mag: float, z: 
         idx = idx.to(device=t.device, dtype=torch.int32).reshape(R, 3, nz).contiguous()
     if z is not None:
         z = z.to(device=t.device, dtype=torch.float64).reshape(R, 3, nz).contiguous()
-    check(lib.shm_sim_sensor_fault(C.c_void_p(t.data_ptr()), int(t.dtype == torch.float32), R, steps, nd, k, int(dof), C.c_double(rel_mag),
+    out = torch.empty_like(t)
+    check(lib.shm_sim_sensor_fault(C.c_void_p(t.data_ptr()), C.c_void_p(out.data_ptr()), int(t.dtype == torch.float32), R, steps, nd, k, int(dof), C.c_double(rel_mag),
                                    C.c_void_p(z.data_ptr()) if z is not None and nz else None,
                                    C.c_void_p(idx.data_ptr()) if idx is not None and nz else None, nz, _stream()), "shm_sim_sensor_fault")
-    return t[0] if squeeze else t
+    return out[0] if squeeze else out
 
 
 # the four sensor-fault datasets of 02_generate_fault_datasets.py:193-198
@@ -245,3 +246,21 @@ def save_csv(table: torch.Tensor, path) -> Path:
     arr = table.detach().cpu().numpy()
     np.savetxt(str(path), arr, delimiter=",", header=",".join(columns(arr.shape[1] // 3)), comments="", fmt="%.17g" if arr.dtype == np.float64 else "%.9g")
     return path
+
+
+def write_dataset(root, n_normal: int = 10, base_seed: int = 2025, normal_rms: float = 50.0, fault_rms: float = 200.0, fault_seed: int = 42,
+                  jitter_seed: int | None = None, seed: int = 0, device="cuda") -> Dict[str, List[Path]]:
+    """Everything 01_generate_normal_runs.py and 02_generate_fault_datasets.py leave under <root>/Data/raw (plots excluded), from two
+    launches: normal/normal_seed<k>.csv, faults/structural_fault/<label>/<label>.csv, faults/sensor_fault/<name>/<name>.csv.
+    Tables are integrated and written in fp64 like the reference's DataFrames."""
+    root = Path(root)
+    written: Dict[str, List[Path]] = {"normal": [], "structural_fault": [], "sensor_fault": []}
+    tables, _ = normal_runs(n_normal, base_seed, normal_rms, jitter_seed, device, dtype=torch.float64)
+    for i in range(n_normal):
+        written["normal"].append(save_csv(tables[i], root / f"Data/raw/normal/normal_seed{base_seed + i}.csv"))
+    _, structural, sensor = fault_datasets(fault_rms, fault_seed, seed, device, dtype=torch.float64)
+    for label, tab in structural.items():
+        written["structural_fault"].append(save_csv(tab, root / f"Data/raw/faults/structural_fault/{label}/{label}.csv"))
+    for name, tab in sensor.items():
+        written["sensor_fault"].append(save_csv(tab, root / f"Data/raw/faults/sensor_fault/{name}/{name}.csv"))
+    return written

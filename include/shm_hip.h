@@ -208,8 +208,9 @@ int     shm_olcnn_forward(const shm_olcnn_config* cfg, const float* params, cons
  * 02_generate_fault_datasets.py:152-170).  out [R][steps][3 nd] = x_1..x_nd, v_1..v_nd, a_1..a_nd per step (the reference's
  * DataFrame columns), fp64, or fp32 if out_f32 != 0; states are clipped to +-1e5 as in :131-133.  nd 1..6.
  *
- * shm_sim_sensor_fault: generate_sensor_faults (02_generate_fault_datasets.py:128-149,190-213) in place on table [R][steps][3 nd]
- * (fp32 if is_f32 != 0, else fp64): columns x_dof, v_dof, a_dof (dof 1-based) of every run get
+ * shm_sim_sensor_fault: generate_sensor_faults (02_generate_fault_datasets.py:128-149,190-213): dst = src [R][steps][3 nd] (fp32 if
+ * is_f32 != 0, else fp64; dst may be src for an in-place update, otherwise the buffers must not overlap) with the columns x_dof, v_dof,
+ * a_dof (dof 1-based) of every run corrupted:
  *   kind 0 noise  + mag * z[r][j][t]                      (z standard normal, [R][3][nz = steps])
  *   kind 1 spikes + mag + mag/4 * z[r][j][s] at row idx[r][j][s]   ([R][3][nz], positions distinct per column)
  *   kind 2 drift  + linspace(0, mag, steps)[t]
@@ -218,7 +219,7 @@ int     shm_olcnn_forward(const shm_olcnn_config* cfg, const float* params, cons
 int shm_sim_smooth_force(const double* base, int32_t R, int32_t steps, int32_t nd, int32_t window, float* force, void* stream);
 int shm_sim_newmark(const double* sys, const float* force, int32_t shared_force, int32_t R, int32_t steps, int32_t nd,
                     double dt, double beta, double gamma, void* out, int32_t out_f32, void* stream);
-int shm_sim_sensor_fault(void* table, int32_t is_f32, int32_t R, int32_t steps, int32_t nd, int32_t kind, int32_t dof,
+int shm_sim_sensor_fault(const void* src, void* dst, int32_t is_f32, int32_t R, int32_t steps, int32_t nd, int32_t kind, int32_t dof,
                          double rel_mag, const double* z, const int32_t* idx, int32_t nz, void* stream);
 
 #ifdef __cplusplus

@@ -176,3 +176,25 @@ def test_argument_errors():
         sim.run_simulation(c, torch.zeros(7, 4, device="cuda"))                          # wrong step count
     with pytest.raises(RuntimeError):
         sim.inject_sensor_fault(torch.zeros(10, 12, device="cuda"), "bias", 5, 1.0)      # dof outside 1..4
+
+
+def test_scripts_generate_a_trainable_root(tmp_path):
+    """01 -> 02 -> 00 leave the reference's directory layout; 03 then trains on it (one epoch) without any other input."""
+    import json
+    import subprocess
+    import sys
+
+    from conftest import PKG
+    for mod, extra in (("Scripts.01_generate_normal_runs", ["--runs", "3", "--jitter-seed", "1"]), ("Scripts.02_generate_fault_datasets", []),
+                       ("Scripts.00_make_run_splits", []), ("Scripts.03_train_vae", ["--epochs", "1"])):
+        r = subprocess.run([sys.executable, "-m", mod, "--root", str(tmp_path), *extra], cwd=str(PKG), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (mod, r.stderr[-2000:])
+    assert sorted(p.name for p in (tmp_path / "Data/raw/normal").glob("*.csv")) == ["normal_seed2025.csv", "normal_seed2026.csv", "normal_seed2027.csv"]
+    assert (tmp_path / "Data/raw/faults/structural_fault/stiff_red_40pct/stiff_red_40pct.csv").exists()
+    assert (tmp_path / "Data/raw/faults/sensor_fault/spikes_x1/spikes_x1.csv").exists()
+    sp = json.loads((tmp_path / "Data/processed/run_splits.json").read_text())
+    assert sp["totals"]["normal"] == {"train": 3 * 360, "val": 3 * 270, "test": 3 * 272}
+    assert len(sp["sensor_fault"]["files"]) == 4 and len(sp["structural_fault"]["files"]) == 4
+    assert (tmp_path / "models/temporal_vae_state_dict.pt").exists()
+    header = (tmp_path / "Data/raw/normal/normal_seed2025.csv").read_text().splitlines()[0]
+    assert header == "x1,x2,x3,x4,v1,v2,v3,v4,a1,a2,a3,a4"

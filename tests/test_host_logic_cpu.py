@@ -1,4 +1,6 @@
 """CPU tests of the host-side rows: KL schedules (a7) and data preparation (a9) against the reference goldens."""
+from pathlib import Path
+
 import numpy as np
 import pytest
 
@@ -76,3 +78,39 @@ def test_stitch_windows_and_segment_rmse_match_the_reference_loops():
     yt, yp = rng.standard_normal((23, 2)), rng.standard_normal((23, 2))
     exp = [float(np.sqrt(np.mean((yp[i:min(i + 5, 23)] - yt[i:min(i + 5, 23)]) ** 2))) for i in range(0, 23, 5)]
     assert np.allclose(dataprep.segment_rmse(yt, yp, 5), exp, rtol=0, atol=1e-15)
+
+
+def test_run_splits_match_reference(tmp_path):
+    """dataprep.make_run_splits against the JSON the reference's 00_make_run_splits.py wrote for the same tree (golden)."""
+    import json
+    from shm_hip import dataprep
+    g = json.loads((Path(__file__).parent / "golden" / "run_splits_small.json").read_text())
+    for rel, n in g["rows"].items():
+        p = tmp_path / rel
+        p.parent.mkdir(parents=True, exist_ok=True)
+        p.write_text("x1,x2\n" + "".join("0.0,1.0\n" for _ in range(n)))
+    got = dataprep.make_run_splits(tmp_path, seq_len=100, stride=1)
+    want = g["splits"]
+    assert json.loads((tmp_path / "Data/processed/run_splits.json").read_text()) == got
+    for key in ("mode", "seed", "seq_len", "stride", "totals"):
+        assert got[key] == want[key], key
+    assert got["fractions"] == pytest.approx(want["fractions"])
+    for grp in ("normal", "sensor_fault", "structural_fault"):
+        assert got[grp]["files"] == want[grp]["files"]
+        assert got[grp]["window_indices"] == want[grp]["window_indices"]
+
+
+def test_chain_matrices_match_reference():
+    """simulate.chain_matrices (batched host side of the device integrator) against compute_matrices outputs in the golden."""
+    from shm_hip import simulate as sim
+    G = np.load(Path(__file__).parent / "golden" / "simulation_4dof.npz")
+    tags = ["normal", "jitter", "stiff60"]
+    m, C, K = sim.chain_matrices([G["mass_" + t] for t in tags], [G["stiff_" + t] for t in tags], [float(G["zeta_" + t]) for t in tags])
+    for i, t in enumerate(tags):
+        assert np.array_equal(np.diag(m[i]), G["M_" + t])
+        np.testing.assert_allclose(K[i], G["K_" + t], rtol=1e-15)
+        np.testing.assert_allclose(C[i], G["C_" + t], rtol=1e-10)
+    sys = sim.pack_systems([sim.default_system_config()] * 2)
+    assert sys.shape == (2, 4 + 32) and np.array_equal(sys[0], sys[1])
+    Keff = 4e4 * np.diag(sys[0, :4]) + 200.0 * sys[0, 4:20].reshape(4, 4) + G["K_normal"]
+    np.testing.assert_allclose(sys[0, 20:].reshape(4, 4) @ Keff, np.eye(4), atol=1e-12)
