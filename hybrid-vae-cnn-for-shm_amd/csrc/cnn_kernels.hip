@@ -443,66 +443,66 @@ int cnn_conv_fwd(int layer, int B, int H, int W, const float* x, const float* w,
     if (layer == 1) {
         const size_t lds = sizeof(float) * (((2 * HW + 3) & ~3) + 2 * 9 * 16 + 4);
         if (part) { if ((rc = opt_in_lds(conv3x3_fwd_kernel<2, 16, true>, lds))) return rc;
-                    hipLaunchKernelGGL((conv3x3_fwd_kernel<2, 16, true>), dim3(B), dim3(256), lds, s, x, w, bias, y, part, H, W); }
+                    SHM_LAUNCH((conv3x3_fwd_kernel<2, 16, true>), dim3(B), dim3(256), lds, s, x, w, bias, y, part, H, W); }
         else { if ((rc = opt_in_lds(conv3x3_fwd_kernel<2, 16, false>, lds))) return rc;
-               hipLaunchKernelGGL((conv3x3_fwd_kernel<2, 16, false>), dim3(B), dim3(256), lds, s, x, w, bias, y, part, H, W); }
+               SHM_LAUNCH((conv3x3_fwd_kernel<2, 16, false>), dim3(B), dim3(256), lds, s, x, w, bias, y, part, H, W); }
     } else {
         const size_t lds = sizeof(float) * (((16 * HW + 3) & ~3) + 16 * 9 * 32 + 4);
         if (part) { if ((rc = opt_in_lds(conv3x3_fwd_kernel<16, 32, true>, lds))) return rc;
-                    hipLaunchKernelGGL((conv3x3_fwd_kernel<16, 32, true>), dim3(B), dim3(256), lds, s, x, w, bias, y, part, H, W); }
+                    SHM_LAUNCH((conv3x3_fwd_kernel<16, 32, true>), dim3(B), dim3(256), lds, s, x, w, bias, y, part, H, W); }
         else { if ((rc = opt_in_lds(conv3x3_fwd_kernel<16, 32, false>, lds))) return rc;
-               hipLaunchKernelGGL((conv3x3_fwd_kernel<16, 32, false>), dim3(B), dim3(256), lds, s, x, w, bias, y, part, H, W); }
+               SHM_LAUNCH((conv3x3_fwd_kernel<16, 32, false>), dim3(B), dim3(256), lds, s, x, w, bias, y, part, H, W); }
     }
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
 int cnn_bn_finalize(int C, int B, long long n, int train, const float* part, const float* gamma, const float* beta, float* run_mean,
                     float* run_var, float* mean, float* rstd, float* scale, float* shift, hipStream_t s) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, s, C, B, n, train, part, gamma, beta, run_mean, run_var, mean, rstd, scale, shift);
+    SHM_LAUNCH(bn_finalize_kernel, dim3(C), dim3(64), 0, s, C, B, n, train, part, gamma, beta, run_mean, run_var, mean, rstd, scale, shift);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
 int cnn_bn_relu_pool(int B, int C, int H, int W, const float* y, const float* scale, const float* shift, float* out, unsigned char* idx, hipStream_t s) {
-    hipLaunchKernelGGL(bn_relu_pool_kernel, dim3(B), dim3(256), 0, s, C, H, W, y, scale, shift, out, idx);
+    SHM_LAUNCH(bn_relu_pool_kernel, dim3(B), dim3(256), 0, s, C, H, W, y, scale, shift, out, idx);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
 int cnn_linear_fwd(int B, int F, int O, const float* in, const float* Wt, const float* bias, float* pre, float* out, int relu, float drop_p,
                    uint64_t seed, hipStream_t s) {
-    hipLaunchKernelGGL(linear_fwd_kernel, dim3(ceil_div(O, 32), ceil_div(B, 8)), dim3(256), 0, s, B, F, O, in, Wt, bias, pre, out, relu, drop_p,
+    SHM_LAUNCH(linear_fwd_kernel, dim3(ceil_div(O, 32), ceil_div(B, 8)), dim3(256), 0, s, B, F, O, in, Wt, bias, pre, out, relu, drop_p,
                        (unsigned long long)seed);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
 int cnn_linear_bwd_dx(int B, int F, int O, const float* dy, const float* Wt, const float* pre, float* dx, float drop_p, uint64_t seed, hipStream_t s) {
     const size_t n = (size_t)B * F;
-    hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, B, F, O, dy, Wt, pre, dx, drop_p, (unsigned long long)seed);
+    SHM_LAUNCH(linear_bwd_dx_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, B, F, O, dy, Wt, pre, dx, drop_p, (unsigned long long)seed);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
 int cnn_ce_loss(int B, int NC, const float* logits, const long long* labels, float* dlogits, float* loss, hipStream_t s) {
-    hipLaunchKernelGGL(ce_loss_kernel, dim3(1), dim3(256), 0, s, B, NC, logits, labels, dlogits, loss);
+    SHM_LAUNCH(ce_loss_kernel, dim3(1), dim3(256), 0, s, B, NC, logits, labels, dlogits, loss);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
 int cnn_softmax_argmax(int B, int NC, const float* logits, long long* cls, float* p1, hipStream_t s) {
-    hipLaunchKernelGGL(softmax_argmax_kernel, dim3(ceil_div(B, 256)), dim3(256), 0, s, B, NC, logits, cls, p1);
+    SHM_LAUNCH(softmax_argmax_kernel, dim3(ceil_div(B, 256)), dim3(256), 0, s, B, NC, logits, cls, p1);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
 int cnn_build_input(int B, int TD, const float* z, const float* zhat, float* xin, hipStream_t s) {
     const size_t n = (size_t)B * TD;
-    hipLaunchKernelGGL(build_input_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, B, TD, z, zhat, xin);
+    SHM_LAUNCH(build_input_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, B, TD, z, zhat, xin);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
 int cnn_bn_bwd(int B, int C, int H, int W, const float* dp, const unsigned char* idx, const float* y, const float* mean, const float* rstd,
                const float* gamma, float* part, float* k1, float* k2, float* dgamma, float* dbeta, float* dy, hipStream_t s) {
-    hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(B), dim3(256), 0, s, C, H, W, dp, idx, y, mean, rstd, part);
+    SHM_LAUNCH(bn_bwd_stats_kernel, dim3(B), dim3(256), 0, s, C, H, W, dp, idx, y, mean, rstd, part);
     SHM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, C, B, (long long)B * H * W, part, k1, k2, dgamma, dbeta);
+    SHM_LAUNCH(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, C, B, (long long)B * H * W, part, k1, k2, dgamma, dbeta);
     SHM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(B), dim3(256), 0, s, C, H, W, dp, idx, y, mean, rstd, gamma, k1, k2, dy);
+    SHM_LAUNCH(bn_bwd_apply_kernel, dim3(B), dim3(256), 0, s, C, H, W, dp, idx, y, mean, rstd, gamma, k1, k2, dy);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
@@ -510,7 +510,7 @@ int cnn_conv_bwd_data2(int B, int H, int W, const float* dy, const float* w, flo
     const size_t lds = sizeof(float) * ((size_t)32 * H * W + 32 * 9 * 16);
     int rc = opt_in_lds(conv3x3_bwd_data_kernel<16, 32>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL((conv3x3_bwd_data_kernel<16, 32>), dim3(B), dim3(256), lds, s, dy, w, dx, H, W);
+    SHM_LAUNCH((conv3x3_bwd_data_kernel<16, 32>), dim3(B), dim3(256), lds, s, dy, w, dx, H, W);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
@@ -519,11 +519,11 @@ int cnn_conv_bwd_weight(int layer, int B, int H, int W, const float* dy, const f
     if (layer == 1) {
         const size_t lds = sizeof(float) * ((size_t)(16 + 2) * H * W + 2 + 8 * 32 * 9);
         if ((rc = opt_in_lds(conv3x3_bwd_weight_kernel<2, 16>, lds))) return rc;
-        hipLaunchKernelGGL((conv3x3_bwd_weight_kernel<2, 16>), dim3(B), dim3(256), lds, s, dy, x, part, H, W);
+        SHM_LAUNCH((conv3x3_bwd_weight_kernel<2, 16>), dim3(B), dim3(256), lds, s, dy, x, part, H, W);
     } else {
         const size_t lds = sizeof(float) * ((size_t)(32 + 16) * H * W + 16);
         if ((rc = opt_in_lds(conv3x3_bwd_weight_kernel<16, 32>, lds))) return rc;
-        hipLaunchKernelGGL((conv3x3_bwd_weight_kernel<16, 32>), dim3(B), dim3(256), lds, s, dy, x, part, H, W);
+        SHM_LAUNCH((conv3x3_bwd_weight_kernel<16, 32>), dim3(B), dim3(256), lds, s, dy, x, part, H, W);
     }
     SHM_LAUNCH_CHECK();
     return SHM_OK;

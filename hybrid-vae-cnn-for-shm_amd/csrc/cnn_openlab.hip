@@ -257,7 +257,7 @@ extern "C" int shm_olcnn_forward(const shm_olcnn_config* cfg, const float* param
     auto P = [&](int i) { return params + lay[i].offset; };
     for (int i = 0; i < 4; ++i) {
         const int ck = bl[i].cin * bl[i].kt * 3, n = bl[i].cout * ck;
-        hipLaunchKernelGGL(ol_weight_relayout_kernel, dim3((n + 255) / 256), dim3(256), 0, s, P(4 * i), reinterpret_cast<float*>(wsb + w.wt[i]), bl[i].cout, ck);
+        SHM_LAUNCH(ol_weight_relayout_kernel, dim3((n + 255) / 256), dim3(256), 0, s, P(4 * i), reinterpret_cast<float*>(wsb + w.wt[i]), bl[i].cout, ck);
         SHM_LAUNCH_CHECK();
     }
     OlHead hd;
@@ -270,13 +270,13 @@ extern "C" int shm_olcnn_forward(const shm_olcnn_config* cfg, const float* param
     for (int i = 0; i < 4; ++i) {
         const float* wt = reinterpret_cast<const float*>(wsb + w.wt[i]);
         if (i < 3) {
-            hipLaunchKernelGGL(ol_block_kernel<false>, dim3(B), dim3(256), 0, s, in, wt, P(4 * i + 1), P(4 * i + 2), P(4 * i + 3), y, pp[i & 1],
+            SHM_LAUNCH(ol_block_kernel<false>, dim3(B), dim3(256), 0, s, in, wt, P(4 * i + 1), P(4 * i + 2), P(4 * i + 3), y, pp[i & 1],
                                bl[i].cin, bl[i].cout, bl[i].kt, H, W, hd);
             in = pp[i & 1];
             H /= 2;
         } else {
             SHM_REQUIRE(H >= 1, SHM_EINVAL, "olcnn_forward: seq_len too short");
-            hipLaunchKernelGGL(ol_block_kernel<true>, dim3(B), dim3(256), 0, s, in, wt, P(4 * i + 1), P(4 * i + 2), P(4 * i + 3), y, (float*)nullptr,
+            SHM_LAUNCH(ol_block_kernel<true>, dim3(B), dim3(256), 0, s, in, wt, P(4 * i + 1), P(4 * i + 2), P(4 * i + 3), y, (float*)nullptr,
                                bl[i].cin, bl[i].cout, bl[i].kt, H, W, hd);
         }
         SHM_LAUNCH_CHECK();

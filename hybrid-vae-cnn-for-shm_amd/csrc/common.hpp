@@ -26,6 +26,14 @@ void set_error(const char* fmt, ...);
         if (!(cond)) { shm::set_error(__VA_ARGS__); return (code); }                      \
     } while (0)
 
+// hipGetLastError() reports the last error of ANY HIP call on this host thread, including calls other libraries in the process
+// (PyTorch) made earlier and never looked at.  Every launch therefore clears the slot first, so that SHM_LAUNCH_CHECK() sees this
+// launch's status and nothing older.
+#define SHM_LAUNCH(...)                                                                   \
+    do {                                                                                  \
+        (void)hipGetLastError();                                                          \
+        hipLaunchKernelGGL(__VA_ARGS__);                                                  \
+    } while (0)
 #define SHM_LAUNCH_CHECK() SHM_HIP_CHECK(hipGetLastError())
 
 // ---------------------------------------------------------------- MFMA wrappers (gfx950)

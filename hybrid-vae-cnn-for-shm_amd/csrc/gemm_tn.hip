@@ -137,9 +137,9 @@ int launch_gemm_tn_f32(const GemmTnArgs& a, hipStream_t s, ReduceJobs* defer) {
 #define SHM_GEMM_LAUNCH(TA, TB)                                                                                              \
     do {                                                                                                                     \
         if (g.narrow)                                                                                                        \
-            hipLaunchKernelGGL((gemm_tn_f32_kernel<1, 1, 4, 1, TA, TB>), grid, dim3(256), 0, s, a, g.tiles_n, g.rows_per_split, g.nsplit); \
+            SHM_LAUNCH((gemm_tn_f32_kernel<1, 1, 4, 1, TA, TB>), grid, dim3(256), 0, s, a, g.tiles_n, g.rows_per_split, g.nsplit); \
         else                                                                                                                 \
-            hipLaunchKernelGGL((gemm_tn_f32_kernel<2, 2, 2, 2, TA, TB>), grid, dim3(256), 0, s, a, g.tiles_n, g.rows_per_split, g.nsplit); \
+            SHM_LAUNCH((gemm_tn_f32_kernel<2, 2, 2, 2, TA, TB>), grid, dim3(256), 0, s, a, g.tiles_n, g.rows_per_split, g.nsplit); \
     } while (0)
     if (a.a_bf16 && a.b_bf16) SHM_GEMM_LAUNCH(bf16_t, bf16_t);
     else if (a.a_bf16) SHM_GEMM_LAUNCH(bf16_t, float);

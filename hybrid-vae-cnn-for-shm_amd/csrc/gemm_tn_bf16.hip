@@ -382,20 +382,20 @@ int launch_gemm_tn_bf16(const GemmTnArgsB& a, hipStream_t s, ReduceJobs* defer) 
         if (a.NB == 2) {
             static bool attr2 = false;
             if (!attr2) { SHM_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tn_bf16_v2_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr2 = true; }
-            hipLaunchKernelGGL((gemm_tn_bf16_v2_kernel<2, false>), dim3(grid), dim3(512), lds, s, a, g.tiles_m, g.rows_per_split, g.nsplit);
+            SHM_LAUNCH((gemm_tn_bf16_v2_kernel<2, false>), dim3(grid), dim3(512), lds, s, a, g.tiles_m, g.rows_per_split, g.nsplit);
         } else if (xp) {
             static bool attrx = false;
             if (!attrx) { SHM_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tn_bf16_v2_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrx = true; }
-            hipLaunchKernelGGL((gemm_tn_bf16_v2_kernel<1, true>), dim3(grid), dim3(512), lds, s, a, g.tiles_m, g.rows_per_split, g.nsplit);
+            SHM_LAUNCH((gemm_tn_bf16_v2_kernel<1, true>), dim3(grid), dim3(512), lds, s, a, g.tiles_m, g.rows_per_split, g.nsplit);
         } else {
             static bool attr1 = false;
             if (!attr1) { SHM_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tn_bf16_v2_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr1 = true; }
-            hipLaunchKernelGGL((gemm_tn_bf16_v2_kernel<1, false>), dim3(grid), dim3(512), lds, s, a, g.tiles_m, g.rows_per_split, g.nsplit);
+            SHM_LAUNCH((gemm_tn_bf16_v2_kernel<1, false>), dim3(grid), dim3(512), lds, s, a, g.tiles_m, g.rows_per_split, g.nsplit);
         }
     } else {
         const int tiles = g.tiles_m * g.tiles_n * a.NB;
         const int grid = round_up(g.nsplit, 8) * tiles;
-        hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(grid), dim3(256), 0, s, a, g.tiles_m, g.tiles_n, g.rows_per_split, g.nsplit);
+        SHM_LAUNCH(gemm_tn_bf16_kernel, dim3(grid), dim3(256), 0, s, a, g.tiles_m, g.tiles_n, g.rows_per_split, g.nsplit);
     }
     SHM_LAUNCH_CHECK();
     if (g.nsplit > 1) {

@@ -486,7 +486,7 @@ int launch_h(const LstmBwdArgsB& a, hipStream_t s) {
     const size_t lds = sizeof(bf16_t) * 2 * 4 * 16 * lds_row_stride(H) + sizeof(float) * ((H / 16) * 64 + (a.dy ? a.Dy * H : 0));
     void (*kern)(LstmBwdArgsB) = a.dy ? (a.Dy == 4 ? lstm_bwd_bf16_kernel<H, 2> : lstm_bwd_bf16_kernel<H, 3>)
                                  : a.dh_seq ? lstm_bwd_bf16_kernel<H, 1> : lstm_bwd_bf16_kernel<H, 0>;
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(4 * H), lds, s, a);
+    SHM_LAUNCH(kern, dim3(tiles), dim3(4 * H), lds, s, a);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
@@ -497,10 +497,10 @@ int launch_dx(const LstmBwdArgsB& a, hipStream_t s) {
     const int tiles_per_wg = n_tiles >= 2048 ? 8 : 1;            // 1024 workgroups at the north-star shape
     const int grid = ceil_div(n_tiles, tiles_per_wg);
     if (a.drop_p > 0.f)
-        hipLaunchKernelGGL((dx_gemm_bf16_kernel<H, true>), dim3(grid), dim3(4 * H), 0, s, a.dpre_seq, a.WxT, a.dx_seq, R, tiles_per_wg,
+        SHM_LAUNCH((dx_gemm_bf16_kernel<H, true>), dim3(grid), dim3(4 * H), 0, s, a.dpre_seq, a.WxT, a.dx_seq, R, tiles_per_wg,
                            a.drop_p, a.drop_seed, a.drop_stack);
     else
-        hipLaunchKernelGGL((dx_gemm_bf16_kernel<H, false>), dim3(grid), dim3(4 * H), 0, s, a.dpre_seq, a.WxT, a.dx_seq, R, tiles_per_wg,
+        SHM_LAUNCH((dx_gemm_bf16_kernel<H, false>), dim3(grid), dim3(4 * H), 0, s, a.dpre_seq, a.WxT, a.dx_seq, R, tiles_per_wg,
                            0.f, a.drop_seed, a.drop_stack);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
@@ -526,7 +526,7 @@ int launch_pair(const LstmBwdPairArgsB& p0, hipStream_t s) {
     if (t.dy) kern = t.Dy == 4 ? (drop ? lstm_bwd_pair_bf16_kernel<H, 2, true> : lstm_bwd_pair_bf16_kernel<H, 2, false>)
                                : (drop ? lstm_bwd_pair_bf16_kernel<H, 3, true> : lstm_bwd_pair_bf16_kernel<H, 3, false>);
     else kern = drop ? lstm_bwd_pair_bf16_kernel<H, 0, true> : lstm_bwd_pair_bf16_kernel<H, 0, false>;
-    hipLaunchKernelGGL(kern, dim3(2 * tiles), dim3(4 * H), lds + 16, s, p);
+    SHM_LAUNCH(kern, dim3(2 * tiles), dim3(4 * H), lds + 16, s, p);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }

@@ -184,7 +184,7 @@ int launch_h(const LstmFwdArgs& a, hipStream_t s) {
     auto kern = (a.drop_p > 0.f) ? lstm_fwd_f32_kernel<H, true> : lstm_fwd_f32_kernel<H, false>;
     if (lds > 48 * 1024)   // opt in to large dynamic LDS (no-op where the runtime does not need it)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(4 * H), lds, s, a);
+    SHM_LAUNCH(kern, dim3(tiles), dim3(4 * H), lds, s, a);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }

@@ -413,7 +413,7 @@ int launch_x(const LstmFwdArgsB& a, hipStream_t s) {
     else
         kern = drop ? (save ? lstm_fwd_bf16_kernel<H, XK, false, true, false, true> : lstm_fwd_bf16_kernel<H, XK, false, true, false, false>)
                     : (save ? lstm_fwd_bf16_kernel<H, XK, false, false, false, true> : lstm_fwd_bf16_kernel<H, XK, false, false, false, false>);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(4 * H), lds, s, a);
+    SHM_LAUNCH(kern, dim3(tiles), dim3(4 * H), lds, s, a);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
@@ -456,7 +456,7 @@ int launch_pair_h(const LstmFwdPairArgsB& p0, hipStream_t s) {
                           : (save ? lstm_fwd_pair_bf16_kernel<H, true, false, true> : lstm_fwd_pair_bf16_kernel<H, true, false, false>);
     else kern = drop ? (save ? lstm_fwd_pair_bf16_kernel<H, false, true, true> : lstm_fwd_pair_bf16_kernel<H, false, true, false>)
                      : (save ? lstm_fwd_pair_bf16_kernel<H, false, false, true> : lstm_fwd_pair_bf16_kernel<H, false, false, false>);
-    hipLaunchKernelGGL(kern, dim3(2 * tiles), dim3(4 * H), lds + 16, s, p);
+    SHM_LAUNCH(kern, dim3(2 * tiles), dim3(4 * H), lds + 16, s, p);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }

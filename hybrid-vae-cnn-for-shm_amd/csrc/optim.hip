@@ -75,13 +75,13 @@ extern "C" int shm_adam_step(int64_t n, float* params, float* grads, float* exp_
     SHM_REQUIRE((reinterpret_cast<uintptr_t>(grads) & 15) == 0, SHM_EINVAL, "shm_adam_step: grads must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     float* partial = (float*)scratch;
-    hipLaunchKernelGGL(sumsq_kernel, dim3(NORM_BLOCKS), dim3(256), 0, s, grads, n, grad_scale, partial);
+    SHM_LAUNCH(sumsq_kernel, dim3(NORM_BLOCKS), dim3(256), 0, s, grads, n, grad_scale, partial);
     SHM_LAUNCH_CHECK();
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     const float step_size = (float)(lr / bc1);
     const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
-    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, n, params, grads, exp_avg, exp_avg_sq, step_size, inv_sqrt_bc2,
+    SHM_LAUNCH(adam_kernel, dim3(blocks), dim3(256), 0, s, n, params, grads, exp_avg, exp_avg_sq, step_size, inv_sqrt_bc2,
                        beta1, beta2, eps, weight_decay, max_norm, grad_scale, partial, out_norm);
     SHM_LAUNCH_CHECK();
     return SHM_OK;

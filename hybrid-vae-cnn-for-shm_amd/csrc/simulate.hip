@@ -249,8 +249,8 @@ template <int ND>
 int launch_newmark(const double* sys, const float* force, long long force_stride, int R, int steps, const NewmarkCoef& k, void* out,
                    int out_f32, hipStream_t s) {
     const dim3 grid((R + SIM_RUNS - 1) / SIM_RUNS), block(SIM_RUNS);
-    if (out_f32) hipLaunchKernelGGL((newmark_kernel<ND, float>), grid, block, 0, s, sys, force, force_stride, R, steps, k, (float*)out);
-    else         hipLaunchKernelGGL((newmark_kernel<ND, double>), grid, block, 0, s, sys, force, force_stride, R, steps, k, (double*)out);
+    if (out_f32) SHM_LAUNCH((newmark_kernel<ND, float>), grid, block, 0, s, sys, force, force_stride, R, steps, k, (float*)out);
+    else         SHM_LAUNCH((newmark_kernel<ND, double>), grid, block, 0, s, sys, force, force_stride, R, steps, k, (double*)out);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
@@ -269,7 +269,7 @@ extern "C" int shm_sim_smooth_force(const double* base, int32_t R, int32_t steps
     SHM_REQUIRE((steps + SMOOTH_SEG - 1) / SMOOTH_SEG <= 65535, SHM_EINVAL, "sim_smooth_force: steps %d too large", steps);
     if (R == 0) return SHM_OK;
     SHM_REQUIRE(base && force, SHM_EINVAL, "sim_smooth_force: NULL base or force");
-    hipLaunchKernelGGL(force_smooth_kernel, dim3(R, (steps + SMOOTH_SEG - 1) / SMOOTH_SEG), dim3(256), lds, (hipStream_t)stream,
+    SHM_LAUNCH(force_smooth_kernel, dim3(R, (steps + SMOOTH_SEG - 1) / SMOOTH_SEG), dim3(256), lds, (hipStream_t)stream,
                        base, steps, nd, window, force);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
@@ -311,8 +311,8 @@ extern "C" int shm_sim_sensor_fault(const void* src, void* dst, int32_t is_f32, 
     if (kind != 1 && kind != 0) nz = 0;
     const dim3 grid(R), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (is_f32) hipLaunchKernelGGL((sensor_fault_kernel<float>), grid, block, 0, s, (const float*)src, (float*)dst, steps, nd, kind, dof, rel_mag, z, idx, nz);
-    else        hipLaunchKernelGGL((sensor_fault_kernel<double>), grid, block, 0, s, (const double*)src, (double*)dst, steps, nd, kind, dof, rel_mag, z, idx, nz);
+    if (is_f32) SHM_LAUNCH((sensor_fault_kernel<float>), grid, block, 0, s, (const float*)src, (float*)dst, steps, nd, kind, dof, rel_mag, z, idx, nz);
+    else        SHM_LAUNCH((sensor_fault_kernel<double>), grid, block, 0, s, (const double*)src, (double*)dst, steps, nd, kind, dof, rel_mag, z, idx, nz);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }

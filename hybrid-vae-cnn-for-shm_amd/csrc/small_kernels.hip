@@ -677,7 +677,7 @@ __global__ void __launch_bounds__(256) bias_sum_kernel(const float* __restrict__
 int launch_head_fwd(int B, int H, int Z, int layer_norm, const float* h_last, const float* eps, const HeadParams& p,
                     const HeadBufs& hb, float* mu_out, float* lv_out, hipStream_t s) {
     SHM_REQUIRE(H <= HMAX && Z <= ZMAX, SHM_EINVAL, "head: H=%d (<=%d) Z=%d (<=%d) unsupported", H, HMAX, Z, ZMAX);
-    hipLaunchKernelGGL(head_fwd_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, s, B, H, Z, layer_norm, h_last, eps, p, hb, mu_out, lv_out);
+    SHM_LAUNCH(head_fwd_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, s, B, H, Z, layer_norm, h_last, eps, p, hb, mu_out, lv_out);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
@@ -685,7 +685,7 @@ int launch_head_bwd(int B, int H, int Z, int layer_norm, const float* dpre_tsum,
                     const float* d_mu, const float* d_lv, const HeadParams& p, const HeadBufs& hb, hipStream_t s) {
     SHM_REQUIRE(H <= HMAX && Z <= ZMAX, SHM_EINVAL, "head: H=%d Z=%d unsupported", H, Z);
     SHM_REQUIRE((4 * H) % HB_WAVES == 0, SHM_EINVAL, "head: 4H = %d must be a multiple of %d", 4 * H, HB_WAVES);
-    hipLaunchKernelGGL(head_bwd_kernel, dim3(ceil_div(B, 4)), dim3(64 * HB_WAVES), 0, s, B, H, Z, layer_norm, dpre_tsum, W_ih_dec0, eps, d_mu, d_lv, p, hb);
+    SHM_LAUNCH(head_bwd_kernel, dim3(ceil_div(B, 4)), dim3(64 * HB_WAVES), 0, s, B, H, Z, layer_norm, dpre_tsum, W_ih_dec0, eps, d_mu, d_lv, p, hb);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
@@ -693,7 +693,7 @@ int launch_head_grads(int B, int H, int Z, int layer_norm, const HeadBufs& hb, f
                       float* lv_w, float* lv_b, float* ln_w, float* ln_b, hipStream_t s) {
     HeadGradPtrs g{l2h_w, l2h_b, mu_w, mu_b, lv_w, lv_b, ln_w, ln_b};
     const int n_total = 3 * H * Z + H + 2 * Z + (layer_norm ? 2 * H : 0);
-    hipLaunchKernelGGL(head_grads_kernel, dim3(ceil_div(n_total, 64)), dim3(256), 0, s, B, H, Z, layer_norm, hb, g);
+    SHM_LAUNCH(head_grads_kernel, dim3(ceil_div(n_total, 64)), dim3(256), 0, s, B, H, Z, layer_norm, hb, g);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
@@ -704,12 +704,12 @@ int launch_out_fwd(int B, int T, int D, int H, const void* h_seq, int h_bf16, co
     if (h_bf16) {
         const int tiles = ceil_div(B, SHM_WPT);
         const bf16_t* hs = (const bf16_t*)h_seq;
-        if (H == 128) hipLaunchKernelGGL(out_fwd_mfma_kernel<128>, dim3(tiles), dim3(64 * OUT_WAVES), 0, s, B, T, D, hs, Wout, bout, x, recon, score, d_recon);
-        else if (H == 64) hipLaunchKernelGGL(out_fwd_mfma_kernel<64>, dim3(tiles), dim3(64 * OUT_WAVES), 0, s, B, T, D, hs, Wout, bout, x, recon, score, d_recon);
-        else hipLaunchKernelGGL(out_fwd_mfma_kernel<32>, dim3(tiles), dim3(64 * OUT_WAVES), 0, s, B, T, D, hs, Wout, bout, x, recon, score, d_recon);
+        if (H == 128) SHM_LAUNCH(out_fwd_mfma_kernel<128>, dim3(tiles), dim3(64 * OUT_WAVES), 0, s, B, T, D, hs, Wout, bout, x, recon, score, d_recon);
+        else if (H == 64) SHM_LAUNCH(out_fwd_mfma_kernel<64>, dim3(tiles), dim3(64 * OUT_WAVES), 0, s, B, T, D, hs, Wout, bout, x, recon, score, d_recon);
+        else SHM_LAUNCH(out_fwd_mfma_kernel<32>, dim3(tiles), dim3(64 * OUT_WAVES), 0, s, B, T, D, hs, Wout, bout, x, recon, score, d_recon);
     }
     else
-        hipLaunchKernelGGL((out_fwd_kernel<float, false>), dim3(B), dim3(256), 0, s, T, D, H, (const float*)h_seq, Wout, bout, x, recon, score);
+        SHM_LAUNCH((out_fwd_kernel<float, false>), dim3(B), dim3(256), 0, s, T, D, H, (const float*)h_seq, Wout, bout, x, recon, score);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
@@ -717,18 +717,18 @@ int launch_vae_loss(int B, int T, int D, int Z, const float* x, const float* rec
                     float kl_w, float* d_recon, float* d_mu, float* d_lv, float* score, float* losses, hipStream_t s) {
     const size_t n = (size_t)B * T * D;
     const int blocks = d_recon ? (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048) : 1;
-    hipLaunchKernelGGL(vae_loss_kernel, dim3(blocks), dim3(256), 0, s, B, T, D, Z, x, recon, mu, lv, score, kl_w, d_recon, d_mu, d_lv, losses);
+    SHM_LAUNCH(vae_loss_kernel, dim3(blocks), dim3(256), 0, s, B, T, D, Z, x, recon, mu, lv, score, kl_w, d_recon, d_mu, d_lv, losses);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
 size_t colsum_scratch_elems(int R, int N) { return (size_t)ceil_div(R, cs_rows(R)) * N; }
 int launch_reduce_partials(const float* partial, int nparts, size_t n, float* out0, float* out1, hipStream_t s) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, partial, nparts, n, n, out0, out1, (float*)nullptr);
+    SHM_LAUNCH(reduce_partials_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, partial, nparts, n, n, out0, out1, (float*)nullptr);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
 int launch_reduce_partials_strided(const float* partial, int nparts, size_t n, size_t stride, float* out0, hipStream_t s) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, partial, nparts, n, stride, out0, (float*)nullptr, (float*)nullptr);
+    SHM_LAUNCH(reduce_partials_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, partial, nparts, n, stride, out0, (float*)nullptr, (float*)nullptr);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
@@ -737,7 +737,7 @@ int launch_window_gather(const float* series, long long n_rows, int D, const int
     if (N == 0) return SHM_OK;
     const size_t total = (size_t)N * T * D;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(window_gather_kernel, dim3(blocks), dim3(256), 0, s, series, n_rows, D, starts, N, T, mean, stdv, clip_z, out);
+    SHM_LAUNCH(window_gather_kernel, dim3(blocks), dim3(256), 0, s, series, n_rows, D, starts, N, T, mean, stdv, clip_z, out);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
@@ -752,33 +752,33 @@ int launch_reduce_batch(ReduceJobs& jobs, hipStream_t s) {
     int blocks = 0;
     for (int i = 0; i < jobs.n; ++i) { jobs.first_block[i] = blocks; blocks += (int)((jobs.job[i].n_out + 31) / 32); }
     jobs.first_block[jobs.n] = blocks;
-    hipLaunchKernelGGL(reduce_batch_kernel, dim3(blocks), dim3(256), 0, s, jobs);
+    SHM_LAUNCH(reduce_batch_kernel, dim3(blocks), dim3(256), 0, s, jobs);
     SHM_LAUNCH_CHECK();
     jobs.n = 0;
     return SHM_OK;
 }
 // partial[split][2][n]: both products of a shared-A GEMM in one launch
 int launch_reduce_partials_pair(const float* partial, int nparts, size_t n, float* outA, float* outB, hipStream_t s) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 31) / 32), 2), dim3(256), 0, s, partial, nparts, n, 2 * n, outA, (float*)nullptr, outB);
+    SHM_LAUNCH(reduce_partials_kernel, dim3((unsigned)((n + 31) / 32), 2), dim3(256), 0, s, partial, nparts, n, 2 * n, outA, (float*)nullptr, outB);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
 
 int launch_colsum(const float* A, int lda, int R, int N, float* out0, float* out1, float* scratch, hipStream_t s) {
     const int chunks = ceil_div(R, cs_rows(R));
-    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 64), chunks), dim3(256), 0, s, A, lda, R, N, scratch);
+    SHM_LAUNCH(colsum_kernel, dim3(ceil_div(N, 64), chunks), dim3(256), 0, s, A, lda, R, N, scratch);
     SHM_LAUNCH_CHECK();
     return launch_reduce_partials(scratch, chunks, (size_t)N, out0, out1, s);
 }
 int launch_pack_fwd_f32(const float* W, int H, int K, float* dst, hipStream_t s) {
     const size_t n = fwd_pack_elems(H, K);
-    hipLaunchKernelGGL(pack_fwd_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, H, K, dst);
+    SHM_LAUNCH(pack_fwd_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, H, K, dst);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
 int launch_pack_bwd_f32(const float* W, int H, int M, float* dst, hipStream_t s) {
     const size_t n = bwd_pack_elems(H, M);
-    hipLaunchKernelGGL(pack_bwd_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, H, M, dst);
+    SHM_LAUNCH(pack_bwd_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, H, M, dst);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
@@ -794,7 +794,7 @@ int launch_narrow_tn(const void* A, int a_bf16, int lda, int M, const float* Bn,
     const int blocks = R < NARROW_BLOCKS * groups * 2 ? ceil_div(R, groups * 2) : NARROW_BLOCKS;
     const int wb = bsum_out ? 1 : 0;
     const size_t stride = (size_t)M * N + (wb ? N : 0);
-#define SHM_NARROW(TA, NM, CP) hipLaunchKernelGGL((narrow_tn_kernel<TA, NM, CP>), dim3(blocks), dim3(256), lds, s, (const TA*)A, lda, M, Bn, N, R, scratch, wb, tile_T, tile_B)
+#define SHM_NARROW(TA, NM, CP) SHM_LAUNCH((narrow_tn_kernel<TA, NM, CP>), dim3(blocks), dim3(256), lds, s, (const TA*)A, lda, M, Bn, N, R, scratch, wb, tile_T, tile_B)
     if (a_bf16) { if (nmax == 4) SHM_NARROW(bf16_t, 4, 8); else SHM_NARROW(bf16_t, 16, 2); }
     else { if (nmax == 4) SHM_NARROW(float, 4, 8); else SHM_NARROW(float, 16, 2); }
 #undef SHM_NARROW
@@ -808,7 +808,7 @@ int launch_narrow_tn(const void* A, int a_bf16, int lda, int M, const float* Bn,
     int rc = launch_reduce_partials(scratch, blocks, stride, red, nullptr, s);
     if (rc) return rc;
     if (trans_out) {
-        hipLaunchKernelGGL(transpose_small_kernel, dim3(ceil_div(N * M, 256)), dim3(256), 0, s, red, N, M, out);
+        SHM_LAUNCH(transpose_small_kernel, dim3(ceil_div(N * M, 256)), dim3(256), 0, s, red, N, M, out);
         SHM_LAUNCH_CHECK();
     } else {
         SHM_HIP_CHECK(hipMemcpyAsync(out, red, sizeof(float) * M * N, hipMemcpyDeviceToDevice, s));
@@ -818,24 +818,24 @@ int launch_narrow_tn(const void* A, int a_bf16, int lda, int M, const float* Bn,
 }
 int launch_pack_fwd_bf16(const float* W, int H, int K, bf16_t* dst, hipStream_t s) {
     const size_t n = fwd_pack_elems_bf16(H, K);
-    hipLaunchKernelGGL(pack_fwd_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, H, K, dst);
+    SHM_LAUNCH(pack_fwd_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, H, K, dst);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
 int launch_pack_bwd_bf16(const float* W, int H, int M, bf16_t* dst, hipStream_t s) {
     const size_t n = bwd_pack_elems_bf16(H, M);
-    hipLaunchKernelGGL(pack_bwd_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, H, M, dst);
+    SHM_LAUNCH(pack_bwd_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, H, M, dst);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
 int launch_pack_all(const PackJobs& jobs, hipStream_t s) {
     if (jobs.n == 0) return SHM_OK;
-    hipLaunchKernelGGL(pack_all_kernel, dim3(64, jobs.n), dim3(256), 0, s, jobs);
+    SHM_LAUNCH(pack_all_kernel, dim3(64, jobs.n), dim3(256), 0, s, jobs);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
 int launch_bias_sum(const float* b_ih, const float* b_hh, int n, float* dst, hipStream_t s) {
-    hipLaunchKernelGGL(bias_sum_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, b_ih, b_hh, n, dst);
+    SHM_LAUNCH(bias_sum_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, b_ih, b_hh, n, dst);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }

@@ -37,6 +37,10 @@ def _load():
         raise ImportError(
             f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             f"(or `make -C {_LIB_PATH.parent}`); this package has no CPU fallback")
+    # PyTorch ships its own libamdhip64 (SONAME libamdhip64.so.7, found through torch's RPATH).  libshm_hip.so asks for the same
+    # SONAME, so it binds to whichever copy is already in the process: import torch FIRST, or the system copy is loaded beside
+    # torch's and the process ends up with two HIP runtimes, the second of which finds no device ("no ROCm-capable device").
+    import torch  # noqa: F401
     lib = C.CDLL(str(_LIB_PATH))
     vp, f32p = C.c_void_p, C.c_void_p
     cfgp = C.POINTER(VaeConfig)

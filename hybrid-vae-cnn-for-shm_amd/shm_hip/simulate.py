@@ -264,3 +264,28 @@ def write_dataset(root, n_normal: int = 10, base_seed: int = 2025, normal_rms: f
     for name, tab in sensor.items():
         written["sensor_fault"].append(save_csv(tab, root / f"Data/raw/faults/sensor_fault/{name}/{name}.csv"))
     return written
+
+
+def s2_windows(n_runs: int = 64, win_len: int = 256, stride: int = 4, train_frac=(0.0, 0.7), val_frac=(0.7, 1.0), base_seed: int = 2025,
+               jitter_seed: int = 0, force_rms: float = 50.0, device="cuda"):
+    """The "S2" realism data of SURVEY.md §8d, built entirely on the device: jittered 4-DOF Newmark runs (displacement channels x1..x4 only,
+    1001 steps), windows of win_len rows every `stride` rows from the train / val time fractions of every run, per-channel z-score
+    from the train windows.  Returns (Ztr [Ntr, win_len, 4], Zva [Nva, win_len, 4], mean [4], std [4]) as fp32 device tensors."""
+    from . import dataprep
+    tables, _ = normal_runs(n_runs, base_seed, force_rms, jitter_seed, device)
+    steps = tables.shape[1]
+    series = tables[:, :, :4].reshape(n_runs * steps, 4).contiguous()          # runs back to back; windows never straddle two runs
+
+    def starts(frac):
+        lo, hi = int(steps * frac[0]), int(steps * frac[1])
+        local = np.arange(lo, hi - win_len + 1, stride, dtype=np.int64)
+        return (np.arange(n_runs, dtype=np.int64)[:, None] * steps + local[None, :]).reshape(-1)
+
+    Wtr = dataprep.device_windows(series, starts(train_frac), win_len)
+    flat = Wtr.reshape(-1, 4).double()
+    mean = flat.mean(0).float()
+    std = flat.std(0, unbiased=False).float()
+    std = torch.where(std == 0, torch.full_like(std, 1e-6), std)
+    Ztr = dataprep.device_windows(series, starts(train_frac), win_len, mean, std)
+    Zva = dataprep.device_windows(series, starts(val_frac), win_len, mean, std)
+    return Ztr, Zva, mean, std

@@ -64,3 +64,20 @@ def test_dropout_mask_replica_statistics():
     buf2 = np.zeros_like(buf)
     _capi.lib.shm_dropout_keep_mask(C.c_uint64(77), 1, 64, 50, 32, C.c_float(0.3), buf2.ctypes.data_as(C.c_void_p))
     assert 0.3 < (buf != buf2).mean() < 0.5                       # independent streams per stack
+
+
+def test_one_hip_runtime_whatever_the_import_order():
+    """PyTorch bundles its own libamdhip64 with the system library's SONAME.  Importing the binding BEFORE torch must not leave two HIP
+    runtimes in the process (the second one finds no device on a GPU box): _capi imports torch first."""
+    import subprocess
+    import sys
+
+    from conftest import PKG
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from shm_hip import _capi\n"
+            "import torch\n"
+            "libs = sorted({l.split()[-1] for l in open('/proc/self/maps').read().splitlines() if 'libamdhip64' in l})\n"
+            "print(len(libs), libs)\n") % str(PKG)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert r.stdout.split()[0] == "1", r.stdout
