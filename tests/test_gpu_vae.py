@@ -194,6 +194,36 @@ def test_ragged_batches_and_tiny_windows_match_oracle(B, T):
     assert maxdiff(r2, recon) < TOL and maxdiff(m2, mu) < TOL and maxdiff(l2, lv) < TOL
 
 
+@pytest.mark.parametrize("precision,layer_norm,H", [("fp32", False, 32), ("fp32", True, 64), ("bf16", False, 32), ("bf16", True, 128)])
+def test_baseline_config0_shape_train_step(precision, layer_norm, H):
+    """BASELINE.json configs[0]: the 1_DOF-style LSTM-VAE on ONE channel, seq_len 128, latent 8 — one fused train step (forward, loss,
+    BPTT, clip, Adam) against the fp64 oracle.  fp32 path: loss 1e-4, gradients 2e-4 of each tensor's max; bf16 path: DESIGN.md §2 bars."""
+    from oracle.vae_oracle import VAEOracle
+    from Scripts.Models.temporal_vae import TemporalVAE
+    from shm_hip.trainer import VAETrainer
+    torch.manual_seed(128)
+    m = TemporalVAE(1, 8, H, 2, 0.0, layer_norm=layer_norm, precision=precision).cuda().train()
+    p0 = {k: v.detach().cpu().numpy().astype(np.float64) for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(37, 128, 1, generator=g)
+    eps = torch.randn(37, 8, generator=g)
+    tr = VAETrainer(m, lr=1e-3, weight_decay=0.0, max_norm=None if not layer_norm else 2.0)
+    stats = tr.step(x.cuda(), 0.25, eps=eps.cuda()).cpu().numpy()
+    tr.engine.check_status()
+    o = VAEOracle(p0, 2, layer_norm)
+    o.forward(x.numpy(), eps.numpy())
+    losses, grads = o.loss_and_grads(0.25)
+    got = dict(zip([k for k, _, _ in tr.engine.layout], tr.engine.split(tr.grads)))
+    if precision == "fp32":
+        assert abs(stats[0] - losses["loss"]) < 1e-4 * max(1.0, losses["loss"])
+        rep = _grad_report(got, grads)
+        assert max(rep.values()) < 2e-4, rep
+    else:
+        assert abs(stats[0] - losses["loss"]) < 5e-4 * max(1.0, losses["loss"])
+        rel = {k: float(np.linalg.norm(got[k].cpu().numpy() - v) / max(np.linalg.norm(v), 1e-12)) for k, v in grads.items()}
+        assert max(rel.values()) < 2e-2, rel
+
+
 def test_cpu_tensor_is_refused():
     g = load_golden("vae_fwd_mini")
     m = build_module(g["cfg"], split_prefix(g, "p."))
