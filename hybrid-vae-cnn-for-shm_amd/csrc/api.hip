@@ -65,6 +65,7 @@ struct shm_vae_plan {
     size_t gemm_partial_elems;
     size_t narrow_scratch;  // block partials of narrow_tn (enc0 dW_ih)
     size_t narrow_scratch2; // block partials of narrow_tn (dW_out): both may be pending in one reduce batch
+    size_t score_part;      // bf16 path: out_fwd's per-part squared-error sums [4][tiles*4]
     size_t pair_sync;       // bf16 path, 2 layers: ticket / progress words of the layer-pipelined launches (zeroed per launch)
     size_t h0_bf;           // bf16 path: bf16 copy of the decoder input h0 [qt*WPT, H], written by decoder layer 0's forward
     size_t x_tb;            // bf16 path: tile-blocked bf16 copy of x [Rq, 16], written by encoder layer 0's forward, read by its dW_ih product
@@ -128,6 +129,9 @@ static int build_layout(const shm_vae_config* c, std::vector<shm_tensor_desc>& o
 
 // Layer-pipelined launches can be switched off (one launch per layer) for A/B measurements and for the bit-identity test:
 // SHM_PAIR_LAUNCH=0 in the environment, or shm_set_pair_launch(0).  Results are bit-identical either way.
+// misc region of the bf16 workspace: [0,64) sticky error word, [64,320) a line of zeros (GEMM operand for invalid rows),
+// [320, ...) one arrival counter per 4-window tile for out_fwd's shared tiles
+static size_t misc_bytes(int B) { return 320 + (((size_t)ceil_div(B, SHM_WPT) * 4 + 63) & ~(size_t)63); }
 static int g_pair_launch = -1;
 static bool pair_launch_enabled() {
     if (g_pair_launch < 0) { const char* e = getenv("SHM_PAIR_LAUNCH"); g_pair_launch = (e && e[0] == '0') ? 0 : 1; }
@@ -246,7 +250,8 @@ extern "C" int shm_vae_plan_create(const shm_vae_config* cfg, int32_t B, int32_t
         }
     }
     if (bf && L == 2) p->pair_sync = take_bytes(2 * lstm_fwd_pair_sync_bytes(B));      // two blocks, used alternately
-    if (bf) p->misc = take_bytes(64 + 256);
+    if (bf) p->misc = take_bytes(misc_bytes(B));                     // sticky error word | 256 B of zeros | out_fwd's per-tile arrival counters
+    if (bf) p->score_part = take((size_t)4 * ceil_div(B, SHM_WPT) * SHM_WPT);
     if (bf) p->x_tb = take_bytes(2 * Rq * 16);
     if (bf) p->h0_bf = take_bytes(2 * qt * SHM_WPT * H);
     p->params_copy = take((size_t)p->n_params);
@@ -316,7 +321,7 @@ extern "C" int shm_vae_pack_weights(shm_vae_plan* p, const float* params, void* 
             j.src = src; j.src2 = src2; j.dst = dst; j.kind = kind; j.H = H; j.K = K;
         };
         add(params, nullptr, at<float>(ws, p->params_copy), 3, (int)p->n_params);
-        add(nullptr, nullptr, at<char>(ws, p->misc), 4, (64 + 256) / 4);                       // sticky error word + zero line
+        add(nullptr, nullptr, at<char>(ws, p->misc), 4, (int)(misc_bytes(p->B) / 4));          // sticky error word + zero line + tile counters
         if (p->pair_sync)                                                                      // the block the next pair launch uses
             add(nullptr, nullptr, at<char>(ws, p->pair_sync + (size_t)p->sync_next * lstm_fwd_pair_sync_bytes(p->B)), 4,
                 (int)(lstm_fwd_pair_sync_bytes(p->B) / 4));
@@ -442,7 +447,9 @@ extern "C" int shm_vae_forward(shm_vae_plan* p, const float* x, const float* eps
         KernelTimer kt("out_fwd", s);
         if ((rc = launch_out_fwd(B, T, D, H, at<char>(ws, p->dec[L - 1].h_seq), c.precision == SHM_PREC_BF16, prm + p->out_w, prm + p->out_b, x, rec,
                                  at<float>(ws, p->score), s,
-                                 (c.precision == SHM_PREC_BF16 && p->training) ? at<float>(ws, p->d_recon) : nullptr))) return rc;
+                                 (c.precision == SHM_PREC_BF16 && p->training) ? at<float>(ws, p->d_recon) : nullptr,
+                                 c.precision == SHM_PREC_BF16 ? at<float>(ws, p->score_part) : nullptr,
+                                 c.precision == SHM_PREC_BF16 ? at<unsigned>(ws, p->misc + 320) : nullptr))) return rc;
     }
     if (score) SHM_HIP_CHECK(hipMemcpyAsync(score, at<float>(ws, p->score), sizeof(float) * B, hipMemcpyDeviceToDevice, s));
     p->recon_ptr = rec;

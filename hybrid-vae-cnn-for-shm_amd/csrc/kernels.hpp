@@ -65,8 +65,9 @@ int launch_head_grads(int B, int H, int Z, int layer_norm, const HeadBufs& hb, f
 
 // ---- output layer + per-window score; loss --------------------------------------------------------------
 // h_bf16: h_seq is bf16 in tile-blocked row order (row of (b,t) = ((b/16)*T + t)*16 + b%16); else fp32 natural [B,T,H]
-int launch_out_fwd(int B, int T, int D, int H, const void* h_seq, int h_bf16, const float* Wout, const float* bout,
-                   const float* x, float* recon, float* score, hipStream_t s, float* d_recon = nullptr);   // d_recon (bf16 path, optional): 2 (recon - x) / (B T D)
+int launch_out_fwd(int B, int T, int D, int H, const void* h_seq, int h_bf16, const float* Wout, const float* bout, const float* x,
+                   float* recon, float* score, hipStream_t s, float* d_recon = nullptr, float* score_part = nullptr,
+                   unsigned* tile_cnt = nullptr);   // bf16: score_part [4][ceil(B/4)*4] + tile_cnt [ceil(B/4)] (zeroed) let several workgroups share a tile   // d_recon (bf16 path, optional): 2 (recon - x) / (B T D)
 int launch_vae_loss(int B, int T, int D, int Z, const float* x, const float* recon, const float* mu, const float* lv,
                     float kl_w, float* d_recon, float* d_mu, float* d_lv, float* score, float* losses, hipStream_t s);
 

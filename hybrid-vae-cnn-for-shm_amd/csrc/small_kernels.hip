@@ -284,7 +284,8 @@ template <int H>
 __global__ void __launch_bounds__(64 * OUT_WAVES) out_fwd_mfma_kernel(int B, int T, int D, const bf16_t* __restrict__ h_seq,
                                                            const float* __restrict__ Wout, const float* __restrict__ bout,
                                                            const float* __restrict__ x, float* __restrict__ recon,
-                                                           float* __restrict__ score, float* __restrict__ d_recon) {
+                                                           float* __restrict__ score, float* __restrict__ d_recon,
+                                                           float* score_part, unsigned* tile_cnt) {
     static_assert(SHM_WPT == 4, "row <-> (step, window) mapping below assumes 4-window tiles");
     constexpr int KS = H / 32;
     __shared__ float red[OUT_WAVES][4][64];
@@ -298,17 +299,21 @@ __global__ void __launch_bounds__(64 * OUT_WAVES) out_fwd_mfma_kernel(int B, int
     }
     const float bias = j < D ? bout[j] : 0.f;
     const int n_groups = (T * 4 + 15) / 16;                           // 16-row groups of this tile (4 steps each)
+    // gridDim.y workgroups share a tile (B = 512 is only 128 tiles on 256 CUs): part y takes a contiguous range of the groups
+    const int part = blockIdx.y, nsplit = gridDim.y;
+    const int per_part = (n_groups + nsplit - 1) / nsplit;
+    const int g_lo = part * per_part, g_hi = min(n_groups, g_lo + per_part);
     const bf16_t* hb = h_seq + (size_t)tile * T * 4 * H;
     float sq[4] = {0.f, 0.f, 0.f, 0.f};
     // GB groups per wave and pass: all their fragment loads (GB x KS x 16 B per lane) are in flight before the first MFMA
     constexpr int GB = 4;
     const bf16x8 zero8 = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
-    for (int g0 = w * GB; g0 < n_groups; g0 += OUT_WAVES * GB) {
+    for (int g0 = g_lo + w * GB; g0 < g_hi; g0 += OUT_WAVES * GB) {
         bf16x8 af[GB][KS];
 #pragma unroll
         for (int gi = 0; gi < GB; ++gi) {
             const int row = (g0 + gi) * 16 + j;                       // A operand row supplied by this lane
-            const bool rv = row < T * 4;
+            const bool rv = row < T * 4 && g0 + gi < g_hi;
             const bf16_t* src = hb + (size_t)(rv ? row : 0) * H + 8 * q;
 #pragma unroll
             for (int s = 0; s < KS; ++s) { const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + 32 * s); af[gi][s] = rv ? v : zero8; }
@@ -320,7 +325,7 @@ __global__ void __launch_bounds__(64 * OUT_WAVES) out_fwd_mfma_kernel(int B, int
 #pragma unroll
             for (int s = 0; s < KS; ++s) acc = mfma_bf16_16x16x32(af[gi][s], wf[s], acc);
             const int t = grp * 4 + q;                                // accumulator rows 4q + r: step t, window r
-            if (j < D && t < T) {
+            if (j < D && t < T && grp < g_hi) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int b = tile * 4 + r;
@@ -339,13 +344,35 @@ __global__ void __launch_bounds__(64 * OUT_WAVES) out_fwd_mfma_kernel(int B, int
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[w][r][lane] = sq[r];
     __syncthreads();
-    if (threadIdx.x < 4 && score) {                                   // fixed-order sum: deterministic
-        const int r = threadIdx.x, b = tile * 4 + r;
-        float tot = 0.f;
+    float tot = 0.f;
+    if (threadIdx.x < 4) {                                            // fixed-order sum: deterministic
+        const int r = threadIdx.x;
         for (int ww = 0; ww < OUT_WAVES; ++ww)
             for (int l = 0; l < 64; ++l) tot += red[ww][r][l];
-        if (b < B) score[b] = tot / (float)(T * D);
     }
+    if (nsplit == 1) {
+        if (threadIdx.x < 4 && score && tile * 4 + (int)threadIdx.x < B) score[tile * 4 + threadIdx.x] = tot / (float)(T * D);
+        return;
+    }
+    // several parts per tile: each leaves its partial sums, the LAST one to arrive adds them in part order (so the result does not
+    // depend on which one that is) and re-arms the counter for the next launch.  Partials cross workgroups, possibly XCDs: they are
+    // stored and loaded as agent-scope atomics (write-through / cache-bypassing), retired with vmcnt(0) before the ticket is taken —
+    // no fence: a release fence here would write back the whole L2 (the recon / d_recon lines this kernel just produced).
+    __shared__ unsigned ticket;
+    const size_t tiles = gridDim.x;
+    if (threadIdx.x < 4) __hip_atomic_store(score_part + ((size_t)part * tiles + tile) * 4 + threadIdx.x, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(tile_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (ticket != (unsigned)(nsplit - 1)) return;
+    if (threadIdx.x < 4) {
+        float sum = 0.f;
+        for (int pp = 0; pp < nsplit; ++pp)
+            sum += __hip_atomic_load(score_part + ((size_t)pp * tiles + tile) * 4 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (score && tile * 4 + (int)threadIdx.x < B) score[tile * 4 + threadIdx.x] = sum / (float)(T * D);
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(tile_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------------------------------------------------ loss + its gradients
@@ -697,16 +724,25 @@ int launch_head_grads(int B, int H, int Z, int layer_norm, const HeadBufs& hb, f
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
+int out_fwd_parts(int B, int T) {
+    const int tiles = ceil_div(B, SHM_WPT), n_groups = (T * 4 + 15) / 16;
+    int n = 256 / tiles;                                              // fill the 256 CUs
+    n = n < 1 ? 1 : (n > 4 ? 4 : n);
+    while (n > 1 && n_groups / n < 8) n >>= 1;                        // but keep at least a wave-pass worth of groups per part
+    return n == 3 ? 2 : n;
+}
 int launch_out_fwd(int B, int T, int D, int H, const void* h_seq, int h_bf16, const float* Wout, const float* bout, const float* x,
-                   float* recon, float* score, hipStream_t s, float* d_recon) {
+                   float* recon, float* score, hipStream_t s, float* d_recon, float* score_part, unsigned* tile_cnt) {
     SHM_REQUIRE(!d_recon || h_bf16, SHM_EINVAL, "out: d_recon is written by the bf16 kernel only");
     SHM_REQUIRE(D <= DMAX && H <= HMAX, SHM_EINVAL, "out: D=%d (<=%d) H=%d unsupported", D, DMAX, H);
     if (h_bf16) {
         const int tiles = ceil_div(B, SHM_WPT);
+        const int parts = (score_part && tile_cnt) ? out_fwd_parts(B, T) : 1;
+        const dim3 grid(tiles, parts);
         const bf16_t* hs = (const bf16_t*)h_seq;
-        if (H == 128) SHM_LAUNCH(out_fwd_mfma_kernel<128>, dim3(tiles), dim3(64 * OUT_WAVES), 0, s, B, T, D, hs, Wout, bout, x, recon, score, d_recon);
-        else if (H == 64) SHM_LAUNCH(out_fwd_mfma_kernel<64>, dim3(tiles), dim3(64 * OUT_WAVES), 0, s, B, T, D, hs, Wout, bout, x, recon, score, d_recon);
-        else SHM_LAUNCH(out_fwd_mfma_kernel<32>, dim3(tiles), dim3(64 * OUT_WAVES), 0, s, B, T, D, hs, Wout, bout, x, recon, score, d_recon);
+        if (H == 128) SHM_LAUNCH(out_fwd_mfma_kernel<128>, grid, dim3(64 * OUT_WAVES), 0, s, B, T, D, hs, Wout, bout, x, recon, score, d_recon, score_part, tile_cnt);
+        else if (H == 64) SHM_LAUNCH(out_fwd_mfma_kernel<64>, grid, dim3(64 * OUT_WAVES), 0, s, B, T, D, hs, Wout, bout, x, recon, score, d_recon, score_part, tile_cnt);
+        else SHM_LAUNCH(out_fwd_mfma_kernel<32>, grid, dim3(64 * OUT_WAVES), 0, s, B, T, D, hs, Wout, bout, x, recon, score, d_recon, score_part, tile_cnt);
     }
     else
         SHM_LAUNCH((out_fwd_kernel<float, false>), dim3(B), dim3(256), 0, s, T, D, H, (const float*)h_seq, Wout, bout, x, recon, score);
