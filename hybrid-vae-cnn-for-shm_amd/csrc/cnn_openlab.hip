@@ -14,6 +14,7 @@
 //      and the two dense layers (256 -> 128 -> classes), all in the same workgroup.
 // fp32 VALU throughout (the parity bar is 1e-4 on the logits; measured ~1e-6); not yet an MFMA kernel.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -39,18 +40,99 @@ __global__ void __launch_bounds__(256) ol_weight_relayout_kernel(const float* __
     if (i < COUT * CK) { const int co = i / CK, r = i - co * CK; wt[(size_t)r * COUT + co] = w[i]; }
 }
 
+// w [COUT][CIN][TAPS] -> wt2 [TAPS][COUT][CIN] (input channel fastest): the A operand of the MFMA convolution
+__global__ void __launch_bounds__(256) ol_weight_relayout_mfma_kernel(const float* __restrict__ w, float* __restrict__ wt2, int COUT, int CIN, int TAPS) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < COUT * CIN * TAPS) {
+        const int tap = i / (COUT * CIN), r = i - tap * COUT * CIN, co = r / CIN, ci = r - co * CIN;
+        wt2[i] = w[((size_t)co * CIN + ci) * TAPS + tap];
+    }
+}
+
+constexpr int OL_THREADS = 512, OL_WAVES = OL_THREADS / 64;
+constexpr int OL_NTW = 7;                   // 16-position tiles a wave accumulates per unit of work (28 accumulator registers)
+constexpr int OL_CPAD = 4;                  // floats of padding per staged position: consecutive positions land on different banks
+constexpr size_t OL_LDS_BUDGET = 96 * 1024; // staged input rows of one chunk
+
+// Convolution of one window on the matrix pipe, exact fp32 (v_mfma_f32_16x16x4_f32): Y[co][pos] = b[co] + sum_{tap, ci} W[tap][co][ci] X[ci][pos + tap].
+// M = 16 output channels, N = 16 consecutive positions (row-major h, w), K = input channels of one tap, 16 per loop trip: lane quarter q
+// owns channels 4q..4q+3 of the trip, so ONE 16-byte LDS read (B operand: the staged input, channel-fastest, zero halo) and ONE 16-byte
+// global read (A operand: wt2) feed four MFMAs.  A wave keeps the accumulators of up to OL_NTW position tiles and reuses every weight
+// fragment for all of them; weight fragments are prefetched one trip ahead.  Rows are processed in chunks of HC so that the staged
+// input fits the LDS budget at any sequence length.
+__device__ __forceinline__ void ol_conv_mfma(const float* __restrict__ xin, const float* __restrict__ wt2, const float* __restrict__ bias,
+                                             float* __restrict__ yb, float* xs, int CIN, int COUT, int KT, int H, int W, int HC) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
+    const int WP = W + 2, CINP = CIN + OL_CPAD, PT = KT / 2, HW = H * W, CB = CIN / 16, trips = KT * 3 * CB;
+    for (int hc0 = 0; hc0 < H; hc0 += HC) {
+        const int hc = min(HC, H - hc0), rows = hc + KT - 1;
+        __syncthreads();                                              // the previous chunk's reads are done
+        for (int e = tid; e < CIN * rows * WP; e += OL_THREADS) {     // global reads walk (row, column) of one channel plane
+            const int ci = e / (rows * WP), rem = e - ci * rows * WP, rr = rem / WP, ww = rem - rr * WP;
+            const int hh = hc0 - PT + rr, wsrc = ww - 1;
+            xs[(rr * WP + ww) * CINP + ci] = (hh >= 0 && hh < H && wsrc >= 0 && wsrc < W) ? xin[(size_t)ci * HW + hh * W + wsrc] : 0.f;
+        }
+        __syncthreads();
+        const int npos = hc * W, ntiles = (npos + 15) / 16, ngroups = (ntiles + OL_NTW - 1) / OL_NTW, mtiles = COUT / 16;
+        for (int u = wave; u < mtiles * ngroups; u += OL_WAVES) {
+            const int mt = u / ngroups, g = u - mt * ngroups, nt0 = g * OL_NTW, ntn = min(OL_NTW, ntiles - nt0), co0 = mt * 16;
+            int pbase[OL_NTW];
+            f32x4 acc[OL_NTW];
+#pragma unroll
+            for (int n = 0; n < OL_NTW; ++n) {
+                const int p = min((nt0 + n) * 16 + j, npos - 1), h = p / W, w0 = p - h * W;
+                pbase[n] = (h * WP + w0) * CINP + 4 * q;                 // tap (dt, df) adds (dt * WP + df) * CINP, trip cb adds 16 * cb
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[n][r] = bias[co0 + 4 * q + r];
+            }
+            const float* wlane = wt2 + (size_t)(co0 + j) * CIN + 4 * q;  // + tap * COUT * CIN + 16 * cb
+            f32x4 a_nxt = *reinterpret_cast<const f32x4*>(wlane);
+            int tap = 0, cb = 0;
+            for (int it = 0; it < trips; ++it) {
+                const f32x4 a = a_nxt;
+                const int dt = tap / 3, df = tap - dt * 3;
+                const int off = (dt * WP + df) * CINP + 16 * cb;
+                if (++cb == CB) { cb = 0; ++tap; }
+                if (it + 1 < trips) a_nxt = *reinterpret_cast<const f32x4*>(wlane + (size_t)tap * COUT * CIN + 16 * cb);
+                f32x4 bv[OL_NTW];
+#pragma unroll
+                for (int n = 0; n < OL_NTW; ++n)
+                    if (n < ntn) bv[n] = *reinterpret_cast<const f32x4*>(xs + pbase[n] + off);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int n = 0; n < OL_NTW; ++n)
+                        if (n < ntn) acc[n] = mfma_f32_16x16x4(a[e], bv[n][e], acc[n]);
+            }
+#pragma unroll
+            for (int n = 0; n < OL_NTW; ++n) {
+                const int p = (nt0 + n) * 16 + j;
+                if (n < ntn && p < npos) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) yb[(size_t)(co0 + 4 * q + r) * HW + hc0 * W + p] = acc[n][r];
+                }
+            }
+        }
+    }
+}
+
 struct OlHead { const float* w1; const float* b1; const float* w2; const float* b2; float* logits; int NC; };
 
 // in [B][CIN][H][W], y scratch [B][COUT][H][W], out [B][COUT][H/2][W] (POOL) or logits (LAST)
 template <bool LAST>
-__global__ void __launch_bounds__(256) ol_block_kernel(const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
+__global__ void __launch_bounds__(OL_THREADS) ol_block_kernel(const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
-                                                       float* __restrict__ out, int CIN, int COUT, int KT, int H, int W, OlHead hd) {
+                                                       float* __restrict__ out, int CIN, int COUT, int KT, int H, int W, int HC, OlHead hd) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];       // MFMA blocks: the staged input chunk
     __shared__ float g_mean[OL_GROUPS], g_rstd[OL_GROUPS];
     __shared__ float feat[256], hid[128];
     const int b = blockIdx.x, tid = threadIdx.x, HW = H * W, PT = KT / 2;
     const float* xin = in + (size_t)b * CIN * HW;
     float* yb = y + (size_t)b * COUT * HW;
+
+    // HC > 0: this block's convolution runs on the matrix pipe (wt is then the [tap][co][ci] layout)
+    if (HC > 0) ol_conv_mfma(xin, wt, bias, yb, xs, CIN, COUT, KT, H, W, HC);
+    else
 
     // ---- pass 1: convolution + bias.  A thread owns 8 consecutive output channels x 4 consecutive rows of one column: per
     // (input channel, column tap) it loads the 4 + KT - 1 input rows it needs once and reuses every weight vector for 4 rows
@@ -58,7 +140,7 @@ __global__ void __launch_bounds__(256) ol_block_kernel(const float* __restrict__
     {
         constexpr int RB = 4, KTMAX = 7;
         const int chunks = COUT / OL_CC, hgroups = (H + RB - 1) / RB;
-        for (int item = tid; item < chunks * W * hgroups; item += 256) {
+        for (int item = tid; item < chunks * W * hgroups; item += OL_THREADS) {
             const int ch = item / (W * hgroups), r0 = item - ch * W * hgroups, hg = r0 / W, w0 = r0 - hg * W;
             const int co0 = ch * OL_CC, h0 = hg * RB;
             float acc[RB][OL_CC];
@@ -106,10 +188,11 @@ __global__ void __launch_bounds__(256) ol_block_kernel(const float* __restrict__
     }
     __syncthreads();
 
-    // ---- pass 2: GroupNorm statistics (biased variance), wave w -> groups 2w, 2w+1
+    // ---- pass 2: GroupNorm statistics (biased variance), wave w -> group w
     {
         const int wv = tid >> 6, lane = tid & 63, cg = COUT / OL_GROUPS, n = cg * HW;
-        for (int g = wv * 2; g < wv * 2 + 2; ++g) {
+        static_assert(OL_WAVES == OL_GROUPS, "one GroupNorm group per wave");
+        for (int g = wv; g < wv + 1; ++g) {
             const float* yg = yb + (size_t)g * n;
             double s = 0.0, q = 0.0;
             for (int i = lane; i < n; i += 64) { const double v = (double)yg[i]; s += v; q += v * v; }
@@ -129,7 +212,7 @@ __global__ void __launch_bounds__(256) ol_block_kernel(const float* __restrict__
     if constexpr (!LAST) {
         const int Hp = H / 2;
         float* ob = out + (size_t)b * COUT * Hp * W;
-        for (int e = tid; e < COUT * Hp * W; e += 256) {
+        for (int e = tid; e < COUT * Hp * W; e += OL_THREADS) {
             const int co = e / (Hp * W), r = e - co * Hp * W, hp = r / W, w0 = r - hp * W, g = co / cg;
             const float sc = gamma[co] * g_rstd[g], sh = beta[co] - g_mean[g] * sc;
             const float v0 = silu(fmaf(yb[(size_t)co * HW + (2 * hp) * W + w0], sc, sh));
@@ -138,7 +221,7 @@ __global__ void __launch_bounds__(256) ol_block_kernel(const float* __restrict__
         }
     } else {
         // AdaptiveAvgPool(1,1): one channel per thread (COUT == 256), fixed order
-        for (int co = tid; co < COUT; co += 256) {
+        for (int co = tid; co < COUT; co += OL_THREADS) {
             const int g = co / cg;
             const float sc = gamma[co] * g_rstd[g], sh = beta[co] - g_mean[g] * sc;
             float s = 0.f;
@@ -255,10 +338,25 @@ extern "C" int shm_olcnn_forward(const shm_olcnn_config* cfg, const float* param
     const OlWs w = ol_ws(cfg, B);
     char* wsb = reinterpret_cast<char*>(ws);
     auto P = [&](int i) { return params + lay[i].offset; };
+    const int W = cfg->num_features;
+    int hc[4];                                          // rows per staged chunk of an MFMA block; 0: vector-ALU block (input channels not a multiple of 16)
+    size_t lds[4];
     for (int i = 0; i < 4; ++i) {
         const int ck = bl[i].cin * bl[i].kt * 3, n = bl[i].cout * ck;
-        SHM_LAUNCH(ol_weight_relayout_kernel, dim3((n + 255) / 256), dim3(256), 0, s, P(4 * i), reinterpret_cast<float*>(wsb + w.wt[i]), bl[i].cout, ck);
+        const size_t row_bytes = (size_t)(W + 2) * (bl[i].cin + OL_CPAD) * sizeof(float);
+        const long fit = (long)(OL_LDS_BUDGET / row_bytes) - (bl[i].kt - 1);
+        const bool mfma = !getenv("SHM_OLCNN_VALU") && bl[i].cin % 16 == 0 && bl[i].cout % 16 == 0 && fit >= 1;
+        hc[i] = mfma ? (int)(fit < cfg->seq_len ? fit : cfg->seq_len) : 0;
+        lds[i] = mfma ? (size_t)(hc[i] + bl[i].kt - 1) * row_bytes : 0;
+        if (mfma) SHM_LAUNCH(ol_weight_relayout_mfma_kernel, dim3((n + 255) / 256), dim3(256), 0, s, P(4 * i), reinterpret_cast<float*>(wsb + w.wt[i]), bl[i].cout, bl[i].cin, bl[i].kt * 3);
+        else      SHM_LAUNCH(ol_weight_relayout_kernel, dim3((n + 255) / 256), dim3(256), 0, s, P(4 * i), reinterpret_cast<float*>(wsb + w.wt[i]), bl[i].cout, ck);
         SHM_LAUNCH_CHECK();
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        SHM_HIP_CHECK(hipFuncSetAttribute((const void*)ol_block_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OL_LDS_BUDGET));
+        SHM_HIP_CHECK(hipFuncSetAttribute((const void*)ol_block_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OL_LDS_BUDGET));
+        attr_set = true;
     }
     OlHead hd;
     hd.w1 = P(16); hd.b1 = P(17); hd.w2 = P(18); hd.b2 = P(19); hd.logits = logits; hd.NC = cfg->num_classes;
@@ -266,18 +364,18 @@ extern "C" int shm_olcnn_forward(const shm_olcnn_config* cfg, const float* param
     float* y = reinterpret_cast<float*>(wsb + w.y);
     float* pp[2] = {reinterpret_cast<float*>(wsb + w.a0), reinterpret_cast<float*>(wsb + w.a1)};
     int H = cfg->seq_len;
-    const int W = cfg->num_features;
     for (int i = 0; i < 4; ++i) {
+        if (hc[i] > H) { lds[i] = (size_t)(H + bl[i].kt - 1) * (W + 2) * (bl[i].cin + OL_CPAD) * sizeof(float); hc[i] = H; }
         const float* wt = reinterpret_cast<const float*>(wsb + w.wt[i]);
         if (i < 3) {
-            SHM_LAUNCH(ol_block_kernel<false>, dim3(B), dim3(256), 0, s, in, wt, P(4 * i + 1), P(4 * i + 2), P(4 * i + 3), y, pp[i & 1],
-                               bl[i].cin, bl[i].cout, bl[i].kt, H, W, hd);
+            SHM_LAUNCH(ol_block_kernel<false>, dim3(B), dim3(OL_THREADS), lds[i], s, in, wt, P(4 * i + 1), P(4 * i + 2), P(4 * i + 3), y, pp[i & 1],
+                               bl[i].cin, bl[i].cout, bl[i].kt, H, W, hc[i], hd);
             in = pp[i & 1];
             H /= 2;
         } else {
             SHM_REQUIRE(H >= 1, SHM_EINVAL, "olcnn_forward: seq_len too short");
-            SHM_LAUNCH(ol_block_kernel<true>, dim3(B), dim3(256), 0, s, in, wt, P(4 * i + 1), P(4 * i + 2), P(4 * i + 3), y, (float*)nullptr,
-                               bl[i].cin, bl[i].cout, bl[i].kt, H, W, hd);
+            SHM_LAUNCH(ol_block_kernel<true>, dim3(B), dim3(OL_THREADS), lds[i], s, in, wt, P(4 * i + 1), P(4 * i + 2), P(4 * i + 3), y, (float*)nullptr,
+                               bl[i].cin, bl[i].cout, bl[i].kt, H, W, hc[i], hd);
         }
         SHM_LAUNCH_CHECK();
     }
