@@ -52,36 +52,41 @@ __global__ void __launch_bounds__(256) ol_weight_relayout_mfma_kernel(const floa
 constexpr int OL_THREADS = 512, OL_WAVES = OL_THREADS / 64;
 constexpr int OL_NTW = 7;                   // 16-position tiles a wave accumulates per unit of work (28 accumulator registers)
 constexpr int OL_CPAD = 4;                  // floats of padding per staged position: consecutive positions land on different banks
-constexpr size_t OL_LDS_BUDGET = 96 * 1024; // staged input rows of one chunk
+constexpr size_t OL_LDS_BUDGET = 72 * 1024; // staged input rows of one chunk: two workgroups per CU (one stages / normalises while the other multiplies)
 
 // Convolution of one window on the matrix pipe, exact fp32 (v_mfma_f32_16x16x4_f32): Y[co][pos] = b[co] + sum_{tap, ci} W[tap][co][ci] X[ci][pos + tap].
 // M = 16 output channels, N = 16 consecutive positions (row-major h, w), K = input channels of one tap, 16 per loop trip: lane quarter q
-// owns channels 4q..4q+3 of the trip, so ONE 16-byte LDS read (B operand: the staged input, channel-fastest, zero halo) and ONE 16-byte
+// owns channels 4q..4q+3 of the trip, so ONE 16-byte LDS read (B operand: the staged input, channel-fastest, zero rows above / below) and ONE 16-byte
 // global read (A operand: wt2) feed four MFMAs.  A wave keeps the accumulators of up to OL_NTW position tiles and reuses every weight
 // fragment for all of them; weight fragments are prefetched one trip ahead.  Rows are processed in chunks of HC so that the staged
 // input fits the LDS budget at any sequence length.
 __device__ __forceinline__ void ol_conv_mfma(const float* __restrict__ xin, const float* __restrict__ wt2, const float* __restrict__ bias,
                                              float* __restrict__ yb, float* xs, int CIN, int COUT, int KT, int H, int W, int HC) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
-    const int WP = W + 2, CINP = CIN + OL_CPAD, PT = KT / 2, HW = H * W, CB = CIN / 16, trips = KT * 3 * CB;
+    const int CINP = CIN + OL_CPAD, PT = KT / 2, HW = H * W, CB = CIN / 16, trips = KT * 3 * CB;
     for (int hc0 = 0; hc0 < H; hc0 += HC) {
         const int hc = min(HC, H - hc0), rows = hc + KT - 1;
         __syncthreads();                                              // the previous chunk's reads are done
-        for (int e = tid; e < CIN * rows * WP; e += OL_THREADS) {     // global reads walk (row, column) of one channel plane
-            const int ci = e / (rows * WP), rem = e - ci * rows * WP, rr = rem / WP, ww = rem - rr * WP;
-            const int hh = hc0 - PT + rr, wsrc = ww - 1;
-            xs[(rr * WP + ww) * CINP + ci] = (hh >= 0 && hh < H && wsrc >= 0 && wsrc < W) ? xin[(size_t)ci * HW + hh * W + wsrc] : 0.f;
+        // staged rows hc0 - PT .. hc0 + hc + PT - 1 (zero outside the window), all W columns, channel-fastest; no column halo: a tap
+        // that leaves the row is masked at the read
+        for (int e = tid; e < CIN * rows * W; e += OL_THREADS) {      // global reads walk (row, column) of one channel plane
+            const int ci = e / (rows * W), rem = e - ci * rows * W, hh = hc0 - PT + rem / W;
+            xs[rem * CINP + ci] = (hh >= 0 && hh < H) ? xin[(size_t)ci * HW + (size_t)(hc0 - PT) * W + rem] : 0.f;
         }
         __syncthreads();
         const int npos = hc * W, ntiles = (npos + 15) / 16, ngroups = (ntiles + OL_NTW - 1) / OL_NTW, mtiles = COUT / 16;
+        const int gsz = (ntiles + ngroups - 1) / ngroups;             // tiles per group, evened out (8 tiles = 4 + 4, not 7 + 1)
         for (int u = wave; u < mtiles * ngroups; u += OL_WAVES) {
-            const int mt = u / ngroups, g = u - mt * ngroups, nt0 = g * OL_NTW, ntn = min(OL_NTW, ntiles - nt0), co0 = mt * 16;
+            const int mt = u / ngroups, g = u - mt * ngroups, nt0 = g * gsz, ntn = min(gsz, ntiles - nt0), co0 = mt * 16;
             int pbase[OL_NTW];
+            unsigned ok_l = 0, ok_r = 0;                              // bit n: this lane's position of tile n has a left / right neighbour column
             f32x4 acc[OL_NTW];
 #pragma unroll
             for (int n = 0; n < OL_NTW; ++n) {
-                const int p = min((nt0 + n) * 16 + j, npos - 1), h = p / W, w0 = p - h * W;
-                pbase[n] = (h * WP + w0) * CINP + 4 * q;                 // tap (dt, df) adds (dt * WP + df) * CINP, trip cb adds 16 * cb
+                const int p = min((nt0 + n) * 16 + j, npos - 1), w0 = p % W;
+                pbase[n] = p * CINP + 4 * q;                          // tap (dt, df) adds (dt * W + df - 1) * CINP, trip cb adds 16 * cb
+                ok_l |= (w0 > 0 ? 1u : 0u) << n;
+                ok_r |= (w0 < W - 1 ? 1u : 0u) << n;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[n][r] = bias[co0 + 4 * q + r];
             }
@@ -91,13 +96,18 @@ __device__ __forceinline__ void ol_conv_mfma(const float* __restrict__ xin, cons
             for (int it = 0; it < trips; ++it) {
                 const f32x4 a = a_nxt;
                 const int dt = tap / 3, df = tap - dt * 3;
-                const int off = (dt * WP + df) * CINP + 16 * cb;
+                const int off = (dt * W + df - 1) * CINP + 16 * cb;
+                const unsigned okm = df == 1 ? ~0u : (df == 0 ? ok_l : ok_r);
                 if (++cb == CB) { cb = 0; ++tap; }
                 if (it + 1 < trips) a_nxt = *reinterpret_cast<const f32x4*>(wlane + (size_t)tap * COUT * CIN + 16 * cb);
                 f32x4 bv[OL_NTW];
 #pragma unroll
                 for (int n = 0; n < OL_NTW; ++n)
-                    if (n < ntn) bv[n] = *reinterpret_cast<const f32x4*>(xs + pbase[n] + off);
+                    if (n < ntn) {
+                        const bool ok = (okm >> n) & 1u;              // masked lanes read their own (valid) position and drop the value
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(xs + pbase[n] + (ok ? off : 0));
+                        bv[n] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -120,7 +130,7 @@ struct OlHead { const float* w1; const float* b1; const float* w2; const float* 
 
 // in [B][CIN][H][W], y scratch [B][COUT][H][W], out [B][COUT][H/2][W] (POOL) or logits (LAST)
 template <bool LAST>
-__global__ void __launch_bounds__(OL_THREADS) ol_block_kernel(const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
+__global__ void __launch_bounds__(OL_THREADS, 4) ol_block_kernel(const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
                                                        float* __restrict__ out, int CIN, int COUT, int KT, int H, int W, int HC, OlHead hd) {
     extern __shared__ __attribute__((aligned(16))) float xs[];       // MFMA blocks: the staged input chunk
@@ -343,7 +353,7 @@ extern "C" int shm_olcnn_forward(const shm_olcnn_config* cfg, const float* param
     size_t lds[4];
     for (int i = 0; i < 4; ++i) {
         const int ck = bl[i].cin * bl[i].kt * 3, n = bl[i].cout * ck;
-        const size_t row_bytes = (size_t)(W + 2) * (bl[i].cin + OL_CPAD) * sizeof(float);
+        const size_t row_bytes = (size_t)W * (bl[i].cin + OL_CPAD) * sizeof(float);
         const long fit = (long)(OL_LDS_BUDGET / row_bytes) - (bl[i].kt - 1);
         const bool mfma = !getenv("SHM_OLCNN_VALU") && bl[i].cin % 16 == 0 && bl[i].cout % 16 == 0 && fit >= 1;
         hc[i] = mfma ? (int)(fit < cfg->seq_len ? fit : cfg->seq_len) : 0;
@@ -365,7 +375,11 @@ extern "C" int shm_olcnn_forward(const shm_olcnn_config* cfg, const float* param
     float* pp[2] = {reinterpret_cast<float*>(wsb + w.a0), reinterpret_cast<float*>(wsb + w.a1)};
     int H = cfg->seq_len;
     for (int i = 0; i < 4; ++i) {
-        if (hc[i] > H) { lds[i] = (size_t)(H + bl[i].kt - 1) * (W + 2) * (bl[i].cin + OL_CPAD) * sizeof(float); hc[i] = H; }
+        if (hc[i] > 0) {                                 // rows per chunk, evened out over the chunks this block's H needs
+            const int nchunks = (H + hc[i] - 1) / hc[i];
+            hc[i] = (H + nchunks - 1) / nchunks;
+            lds[i] = (size_t)(hc[i] + bl[i].kt - 1) * W * (bl[i].cin + OL_CPAD) * sizeof(float);
+        }
         const float* wt = reinterpret_cast<const float*>(wsb + w.wt[i]);
         if (i < 3) {
             SHM_LAUNCH(ol_block_kernel<false>, dim3(B), dim3(OL_THREADS), lds[i], s, in, wt, P(4 * i + 1), P(4 * i + 2), P(4 * i + 3), y, pp[i & 1],
