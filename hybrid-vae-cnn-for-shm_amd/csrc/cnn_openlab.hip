@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(OL_THREADS, 4) ol_block_kernel(const float* __
                                                        float* __restrict__ out, int CIN, int COUT, int KT, int H, int W, int HC, OlHead hd) {
     extern __shared__ __attribute__((aligned(16))) float xs[];       // MFMA blocks: the staged input chunk
     __shared__ float g_mean[OL_GROUPS], g_rstd[OL_GROUPS];
-    __shared__ float feat[256], hid[128];
+    __shared__ float feat[256], hid[128], fpart[OL_THREADS / 256][256];
     const int b = blockIdx.x, tid = threadIdx.x, HW = H * W, PT = KT / 2;
     const float* xin = in + (size_t)b * CIN * HW;
     float* yb = y + (size_t)b * COUT * HW;
@@ -230,19 +230,35 @@ __global__ void __launch_bounds__(OL_THREADS, 4) ol_block_kernel(const float* __
             ob[e] = fmaxf(v0, v1);
         }
     } else {
-        // AdaptiveAvgPool(1,1): one channel per thread (COUT == 256), fixed order
-        for (int co = tid; co < COUT; co += OL_THREADS) {
-            const int g = co / cg;
+        // AdaptiveAvgPool(1,1): OL_THREADS / 256 threads per channel (COUT == 256), each over a contiguous share of the positions; fixed order
+        {
+            constexpr int PARTS = OL_THREADS / 256;
+            const int co = tid % 256, part = tid / 256, g = co / cg;
+            const int per = (HW + PARTS - 1) / PARTS, p0 = part * per, p1 = min(HW, p0 + per);
             const float sc = gamma[co] * g_rstd[g], sh = beta[co] - g_mean[g] * sc;
             float s = 0.f;
-            for (int p = 0; p < HW; ++p) s += silu(fmaf(yb[(size_t)co * HW + p], sc, sh));
-            feat[co] = s / (float)HW;
+            for (int p = p0; p < p1; ++p) s += silu(fmaf(yb[(size_t)co * HW + p], sc, sh));
+            fpart[part][co] = s;
+            __syncthreads();
+            if (tid < 256) {
+                float t = 0.f;
+#pragma unroll
+                for (int pp = 0; pp < PARTS; ++pp) t += fpart[pp][tid];
+                feat[tid] = t / (float)HW;
+            }
         }
         __syncthreads();
-        if (tid < 128) {
-            float a = hd.b1[tid];
-            for (int c = 0; c < 256; ++c) a = fmaf(feat[c], hd.w1[(size_t)tid * 256 + c], a);
-            hid[tid] = silu(a);
+        // Linear(256, 128) + SiLU: a wave per 16 outputs, lanes along the 256 inputs (coalesced weight rows), wave reduction
+        {
+            const int wv = tid >> 6, lane = tid & 63;
+            for (int o = wv * (128 / OL_WAVES); o < (wv + 1) * (128 / OL_WAVES); ++o) {
+                float a = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a = fmaf(feat[lane + 64 * k], hd.w1[(size_t)o * 256 + lane + 64 * k], a);
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+                if (lane == 0) hid[o] = silu(a + hd.b1[o]);
+            }
         }
         __syncthreads();
         if (tid < hd.NC) {
