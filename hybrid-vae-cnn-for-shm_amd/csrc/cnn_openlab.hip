@@ -7,12 +7,13 @@
 //
 // One workgroup per window and block.  GroupNorm needs the statistics of a whole (group, window) slab before anything can be
 // normalised, so a block is three passes of the same workgroup over a per-window scratch slab that stays in L2/MALL:
-//   1. direct convolution (im2col-free): a thread owns 8 consecutive output channels of one output position; the weights
-//      are re-laid [ci][dt][df][co] once per call so that those 8 channels are two 16-byte broadcast loads;
-//   2. per-group mean / rstd (one wave per two groups, fp64 accumulation, fixed order);
+//   1. convolution: blocks whose channel counts are multiples of 16 (2-4: 99 % of the work) run as an implicit GEMM on the matrix
+//      pipe in exact fp32 (ol_conv_mfma below); block 1 (one input channel) is direct vector code, a thread owning 8 output
+//      channels x 4 rows of one column with the weights re-laid [ci][dt][df][co];
+//   2. per-group mean / rstd (one wave per group, fp64 accumulation, fixed order);
 //   3. normalise + affine + SiLU + MaxPool(2,1) into the next block's input — or, in the last block, the global average
 //      and the two dense layers (256 -> 128 -> classes), all in the same workgroup.
-// fp32 VALU throughout (the parity bar is 1e-4 on the logits; measured ~1e-6); not yet an MFMA kernel.
+// fp32 throughout (the parity bar is 1e-4 on the logits; measured ~1e-6).
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
