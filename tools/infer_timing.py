@@ -35,4 +35,17 @@ for (B, T) in ((512, 200), (512, 512), (2048, 200)):
     x = torch.randn(B, 1, T, 4, device="cuda")
     with torch.no_grad():
         d = timeit(lambda: m(x), 5)
-    print(f"openLAB CNN eval B={B} T={T}: {d*1e3:.3f} ms = {B/d:,.0f} windows/s ({B/d*135e6*T/200/1e12:.2f} TFLOP/s fp32 VALU)", flush=True)
+    print(f"openLAB CNN eval B={B} T={T}: {d*1e3:.3f} ms = {B/d:,.0f} windows/s ({B/d*135e6*T/200/1e12:.2f} TFLOP/s fp32)", flush=True)
+
+# openLAB hybrid (10_test_hybrid_pipeline.py:266-302): L = 1 VAE gate on z-scored windows, the openLAB CNN on the anomalous half
+from shm_hip.pipeline import hybrid_predict_openlab
+for T in (200, 512):
+    torch.manual_seed(0)
+    vae = TemporalVAE(4, 8, 64, 1, 0.0, precision="bf16").cuda().eval()
+    m = OlCNN(1, 2, 0.4).cuda().eval()
+    N = 8192
+    Zv = torch.randn(N, T, 4, device="cuda")
+    Xc = torch.randn(N, T, 4, device="cuda")
+    thr = float(score_windows(vae, Zv, 512).median())
+    d = timeit(lambda: hybrid_predict_openlab(vae, m, Zv, Xc, thr, 0.5, 512), 5)
+    print(f"openLAB hybrid N={N} T={T}: VAE gate + CNN on the anomalous half: {N/d:,.0f} windows/s", flush=True)
