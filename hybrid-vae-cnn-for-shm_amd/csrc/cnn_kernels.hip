@@ -427,6 +427,115 @@ __global__ void __launch_bounds__(256) conv3x3_bwd_weight_kernel(const float* __
     }
 }
 
+// The same per-window partial on the matrix pipe, exact fp32 (v_mfma_f32_16x16x4_f32): part[co][n] = sum_p dy[co][p] * col[p][n] with
+// n = ci * 9 + tap and col = the im2col view of x (never materialised): M = 16 output channels, N = 16 (ci, tap) columns, K = positions.
+// dy sits in LDS position-fastest (row stride K + 4: the 16 rows of a fragment land on different banks), so a lane's four k-steps
+// are one 16-byte read; x sits in LDS with a zero halo and a per-position offset table, so a column value is one 4-byte read at
+// table[p] + (ci, tap offset).  With >= 8 output tiles (conv2: 2 x 9) the waves take different tiles; otherwise (conv1: 1 x 2) they
+// split the positions and their accumulators are added in wave order.  Bias gradient: the vector loop of the kernel above.
+template <int CIN, int COUT>
+__global__ void __launch_bounds__(512) conv3x3_bwd_weight_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                      float* __restrict__ part, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int NCOL = CIN * 9, MT = COUT / 16, NT = (NCOL + 15) / 16, NWV = 8, NW_ = COUT * NCOL;
+    constexpr bool TILE_PAR = MT * NT >= NWV;
+    const int HW = H * W, KP = (HW + 15) & ~15, DS = KP + 4, WP = W + 2, XP = (H + 2) * WP, XPP = (CIN * XP + 3) & ~3;
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
+    float* ds = sm;                                           // [COUT][DS], zero beyond HW
+    float* xs = ds + COUT * DS;                               // [CIN][H + 2][W + 2], zero halo
+    int* posoff = reinterpret_cast<int*>(xs + XPP);           // [KP]: (h + 1) * WP + (w + 1) of position p
+    float* red = reinterpret_cast<float*>(posoff + KP);       // position-split only: [NWV][MT * NT][256]
+    for (int e = tid; e < COUT * KP; e += 512) {
+        const int co = e / KP, p = e - co * KP;
+        ds[co * DS + p] = p < HW ? dy[((size_t)b * COUT + co) * HW + p] : 0.f;
+    }
+    for (int e = tid; e < CIN * XP; e += 512) {
+        const int ci = e / XP, r = e - ci * XP, hh = r / WP - 1, ww = r - (hh + 1) * WP - 1;
+        xs[e] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? x[((size_t)b * CIN + ci) * HW + hh * W + ww] : 0.f;
+    }
+    for (int p = tid; p < KP; p += 512) posoff[p] = p < HW ? (p / W + 1) * WP + (p % W + 1) : WP + 1;   // padding: any valid cell (dy is 0 there)
+    __syncthreads();
+    float* out = part + (size_t)b * (NW_ + COUT);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto column = [&](int nt, int& boff, float& keep) {       // this lane's column n = nt * 16 + j of the im2col view
+        const int n = nt * 16 + j, ok = n < NCOL, nn = ok ? n : 0, ci = nn / 9, tap = nn - ci * 9;
+        boff = ci * XP + (tap / 3 - 1) * WP + (tap % 3 - 1);
+        keep = ok ? 1.f : 0.f;
+    };
+    if constexpr (TILE_PAR) {
+        constexpr int G = NWV / MT, NTW = (NT + G - 1) / G;
+        const int mt = wave % MT, g = wave / MT, nt0 = (g * NT) / G, ntn = ((g + 1) * NT) / G - nt0;
+        int boff[NTW]; float keep[NTW]; f32x4 acc[NTW];
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) { column(nt0 + (i < ntn ? i : 0), boff[i], keep[i]); acc[i] = zero4; }
+        const float* arow = ds + (mt * 16 + j) * DS + 4 * q;
+        for (int kb = 0; kb < KP / 16; ++kb) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(arow + kb * 16);
+            const int* pp = posoff + kb * 16 + 4 * q;
+            const int p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3];
+#pragma unroll
+            for (int i = 0; i < NTW; ++i)
+                if (i < ntn) {
+                    const float* xb = xs + boff[i];
+                    acc[i] = mfma_f32_16x16x4(a[0], xb[p0] * keep[i], acc[i]);
+                    acc[i] = mfma_f32_16x16x4(a[1], xb[p1] * keep[i], acc[i]);
+                    acc[i] = mfma_f32_16x16x4(a[2], xb[p2] * keep[i], acc[i]);
+                    acc[i] = mfma_f32_16x16x4(a[3], xb[p3] * keep[i], acc[i]);
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+            const int n = (nt0 + i) * 16 + j;
+            if (i < ntn && n < NCOL) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[(size_t)(mt * 16 + 4 * q + r) * NCOL + n] = acc[i][r];
+            }
+        }
+    } else {
+        constexpr int TILES = MT * NT;
+        int boff[NT]; float keep[NT]; f32x4 acc[TILES];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) column(i, boff[i], keep[i]);
+#pragma unroll
+        for (int i = 0; i < TILES; ++i) acc[i] = zero4;
+        for (int kb = wave; kb < KP / 16; kb += NWV) {
+            const int* pp = posoff + kb * 16 + 4 * q;
+            const int p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3];
+            float bv[NT][4];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const float* xb = xs + boff[i];
+                bv[i][0] = xb[p0] * keep[i]; bv[i][1] = xb[p1] * keep[i]; bv[i][2] = xb[p2] * keep[i]; bv[i][3] = xb[p3] * keep[i];
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(ds + (m * 16 + j) * DS + kb * 16 + 4 * q);
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[m * NT + i] = mfma_f32_16x16x4(a[e], bv[i][e], acc[m * NT + i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TILES; ++i) *reinterpret_cast<f32x4*>(red + ((size_t)(wave * TILES + i) * 64 + lane) * 4) = acc[i];
+        __syncthreads();
+        for (int e = tid; e < TILES * 256; e += 512) {
+            const int tile = e >> 8, l = (e & 255) >> 2, r = e & 3, m = tile / NT, nt = tile - m * NT;
+            const int n = nt * 16 + (l & 15);
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWV; ++w) v += red[(size_t)(w * TILES + tile) * 256 + (e & 255)];
+            if (n < NCOL) out[(size_t)(m * 16 + 4 * (l >> 4) + r) * NCOL + n] = v;
+        }
+    }
+    for (int e = tid; e < COUT; e += 512) {                   // bias gradient of this window
+        const float* dr = ds + e * DS;
+        float acc = 0.f;
+        for (int p = 0; p < HW; ++p) acc += dr[p];
+        out[NW_ + e] = acc;
+    }
+}
+
 template <typename K>
 int opt_in_lds(K kern, size_t lds) {
     SHM_REQUIRE(lds <= 160 * 1024, SHM_EINVAL, "cnn: window needs %zu bytes of LDS (> 160 KiB): T*D too large", lds);
@@ -516,6 +625,21 @@ int cnn_conv_bwd_data2(int B, int H, int W, const float* dy, const float* w, flo
 }
 int cnn_conv_bwd_weight(int layer, int B, int H, int W, const float* dy, const float* x, float* part, hipStream_t s) {
     int rc;
+    // matrix-pipe version unless its staged window does not fit the LDS (or SHM_CNN_VALU_WGRAD is set: measurement knob)
+    const int HW = H * W, KP = (HW + 15) & ~15, XP = (H + 2) * (W + 2);
+    const int cin = layer == 1 ? 2 : 16, cout = layer == 1 ? 16 : 32, tiles = (cout / 16) * ((cin * 9 + 15) / 16);
+    const size_t lds_m = sizeof(float) * ((size_t)cout * (KP + 4) + ((cin * XP + 3) & ~3) + KP + (tiles >= 8 ? 0 : (size_t)8 * tiles * 256));
+    if (lds_m <= 150 * 1024 && !getenv("SHM_CNN_VALU_WGRAD")) {
+        if (layer == 1) {
+            if ((rc = opt_in_lds(conv3x3_bwd_weight_mfma_kernel<2, 16>, lds_m))) return rc;
+            SHM_LAUNCH((conv3x3_bwd_weight_mfma_kernel<2, 16>), dim3(B), dim3(512), lds_m, s, dy, x, part, H, W);
+        } else {
+            if ((rc = opt_in_lds(conv3x3_bwd_weight_mfma_kernel<16, 32>, lds_m))) return rc;
+            SHM_LAUNCH((conv3x3_bwd_weight_mfma_kernel<16, 32>), dim3(B), dim3(512), lds_m, s, dy, x, part, H, W);
+        }
+        SHM_LAUNCH_CHECK();
+        return SHM_OK;
+    }
     if (layer == 1) {
         const size_t lds = sizeof(float) * ((size_t)(16 + 2) * H * W + 2 + 8 * 32 * 9);
         if ((rc = opt_in_lds(conv3x3_bwd_weight_kernel<2, 16>, lds))) return rc;
