@@ -211,11 +211,10 @@ extern "C" int shm_cnn_backward(shm_cnn_plan* p, const float* params, const floa
     {
         // partial rows are [C2*C1*9 weights | C2 biases]; weights and bias are adjacent in neither buffer, so reduce into a
         // scratch row (the tail of wpart's last row is free: reuse colsum scratch sized >= that) then scatter
-        const size_t n = (size_t)C2 * C1 * 9 + C2;
-        float* red = at<float>(ws, p->dp1);               // dp1 is written only by conv_bwd_data below: free as scratch here
-        if ((rc = launch_reduce_partials(wpart, B, n, red, nullptr, s))) return rc;
-        SHM_HIP_CHECK(hipMemcpyAsync(grads + p->c2w, red, sizeof(float) * C2 * C1 * 9, hipMemcpyDeviceToDevice, s));
-        SHM_HIP_CHECK(hipMemcpyAsync(grads + p->c2b, red + C2 * C1 * 9, sizeof(float) * C2, hipMemcpyDeviceToDevice, s));
+        // straight into the two gradient tensors: the weight block and the bias block of every partial row, each with the row stride
+        const size_t nw = (size_t)C2 * C1 * 9, n = nw + C2;
+        if ((rc = launch_reduce_partials_strided(wpart, B, nw, n, grads + p->c2w, s))) return rc;
+        if ((rc = launch_reduce_partials_strided(wpart + nw, B, (size_t)C2, n, grads + p->c2b, s))) return rc;
     }
     if ((rc = cnn_conv_bwd_data2(B, p->H1, p->W1, at<float>(ws, p->dy2), params + p->c2w, at<float>(ws, p->dp1), s))) return rc;
     // block 1
@@ -224,11 +223,9 @@ extern "C" int shm_cnn_backward(shm_cnn_plan* p, const float* params, const floa
                          grads + p->g1, grads + p->b1, at<float>(ws, p->dy1), s))) return rc;
     if ((rc = cnn_conv_bwd_weight(1, B, p->H0, p->W0, at<float>(ws, p->dy1), x, wpart, s))) return rc;
     {
-        const size_t n = (size_t)C1 * 2 * 9 + C1;
-        float* red = at<float>(ws, p->dflat);              // consumed above: free as scratch
-        if ((rc = launch_reduce_partials(wpart, B, n, red, nullptr, s))) return rc;
-        SHM_HIP_CHECK(hipMemcpyAsync(grads + p->c1w, red, sizeof(float) * C1 * 2 * 9, hipMemcpyDeviceToDevice, s));
-        SHM_HIP_CHECK(hipMemcpyAsync(grads + p->c1b, red + C1 * 2 * 9, sizeof(float) * C1, hipMemcpyDeviceToDevice, s));
+        const size_t nw = (size_t)C1 * 2 * 9, n = nw + C1;
+        if ((rc = launch_reduce_partials_strided(wpart, B, nw, n, grads + p->c1w, s))) return rc;
+        if ((rc = launch_reduce_partials_strided(wpart + nw, B, (size_t)C1, n, grads + p->c1b, s))) return rc;
     }
     return SHM_OK;
 }

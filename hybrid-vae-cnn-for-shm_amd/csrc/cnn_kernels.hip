@@ -264,16 +264,16 @@ __global__ void __launch_bounds__(256) build_input_kernel(int B, int TD, const f
 }
 
 // ------------------------------------------------------------------------------------------------ pool/ReLU/BN backward
-// pass A (grid = B): per-channel sums S1 = sum da, S2 = sum da*xhat over this window, da = dp routed to the argmax cell
+// pass A (grid = B): per-channel sums S1 = sum da, S2 = sum da*xhat over this window, da = dp routed to the argmax cell.
+// A wave per channel (channels w, w + 4, ...): wave-level sums only — the block-wide form paid two barriers per channel and sum.
 __global__ void __launch_bounds__(256) bn_bwd_stats_kernel(int C, int H, int W, const float* __restrict__ dp, const unsigned char* __restrict__ idx,
                                                            const float* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            float* __restrict__ part) {
-    __shared__ float red[4];
-    const int Hp = H / 2, Wp = W / 2, b = blockIdx.x, npc = Hp * Wp;
-    for (int c = 0; c < C; ++c) {
+    const int Hp = H / 2, Wp = W / 2, b = blockIdx.x, npc = Hp * Wp, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int c = wv; c < C; c += 4) {
         float s1 = 0.f, s2 = 0.f;
         const float m = mean[c], rs = rstd[c];
-        for (int r = threadIdx.x; r < npc; r += 256) {
+        for (int r = lane; r < npc; r += 64) {
             const size_t e = ((size_t)b * C + c) * npc + r;
             const int k = idx[e];
             if (k < 4) {
@@ -283,9 +283,8 @@ __global__ void __launch_bounds__(256) bn_bwd_stats_kernel(int C, int H, int W, 
                 s1 += g; s2 = fmaf(g, (yv - m) * rs, s2);
             }
         }
-        const float a = block_sum(s1, red);
-        const float q = block_sum(s2, red);
-        if (threadIdx.x == 0) { part[((size_t)b * C + c) * 2] = a; part[((size_t)b * C + c) * 2 + 1] = q; }
+        s1 = wave_sum(s1); s2 = wave_sum(s2);
+        if (lane == 0) { part[((size_t)b * C + c) * 2] = s1; part[((size_t)b * C + c) * 2 + 1] = s2; }
     }
 }
 __global__ void __launch_bounds__(64) bn_bwd_finalize_kernel(int C, int B, long long n_per_channel, const float* __restrict__ part,
