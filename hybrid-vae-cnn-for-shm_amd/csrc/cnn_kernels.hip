@@ -28,7 +28,7 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 }
 
 // ------------------------------------------------------------------------------------------------ conv forward
-// grid = B, block = 256.  LDS: x[CIN][H*W] | w[(ci*9+k)][COUT] | red[4]
+// grid = B, block = 256.  LDS: x[CIN][H*W] | w[(ci*9+k)][COUT] | red[4 waves][COUT][2]
 template <int CIN, int COUT, bool STATS>
 __global__ void __launch_bounds__(256) conv3x3_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ y,
@@ -81,12 +81,17 @@ __global__ void __launch_bounds__(256) conv3x3_fwd_kernel(const float* __restric
         }
     }
     if (STATS) {
+        // wave sums by shuffles, ONE barrier, then a fixed-order sum over the four waves (a block-wide sum per channel and moment
+        // cost 2 x COUT pairs of barriers: most of this kernel's time)
+        const int wv = tid >> 6, lane = tid & 63;
 #pragma unroll
         for (int co = 0; co < COUT; ++co) {
-            const float a = block_sum(s1[co], red);
-            const float q = block_sum(s2[co], red);
-            if (tid == 0) { part[((size_t)b * COUT + co) * 2] = a; part[((size_t)b * COUT + co) * 2 + 1] = q; }
+            const float a = wave_sum(s1[co]), q = wave_sum(s2[co]);
+            if (lane == 0) { red[(wv * COUT + co) * 2] = a; red[(wv * COUT + co) * 2 + 1] = q; }
         }
+        __syncthreads();
+        for (int e = tid; e < 2 * COUT; e += 256)
+            part[(size_t)b * COUT * 2 + e] = (red[e] + red[2 * COUT + e]) + (red[4 * COUT + e] + red[6 * COUT + e]);
     }
 }
 
@@ -549,13 +554,13 @@ int cnn_conv_fwd(int layer, int B, int H, int W, const float* x, const float* w,
     const int HW = H * W;
     int rc;
     if (layer == 1) {
-        const size_t lds = sizeof(float) * (((2 * HW + 3) & ~3) + 2 * 9 * 16 + 4);
+        const size_t lds = sizeof(float) * (((2 * HW + 3) & ~3) + 2 * 9 * 16 + 8 * 16);
         if (part) { if ((rc = opt_in_lds(conv3x3_fwd_kernel<2, 16, true>, lds))) return rc;
                     SHM_LAUNCH((conv3x3_fwd_kernel<2, 16, true>), dim3(B), dim3(256), lds, s, x, w, bias, y, part, H, W); }
         else { if ((rc = opt_in_lds(conv3x3_fwd_kernel<2, 16, false>, lds))) return rc;
                SHM_LAUNCH((conv3x3_fwd_kernel<2, 16, false>), dim3(B), dim3(256), lds, s, x, w, bias, y, part, H, W); }
     } else {
-        const size_t lds = sizeof(float) * (((16 * HW + 3) & ~3) + 16 * 9 * 32 + 4);
+        const size_t lds = sizeof(float) * (((16 * HW + 3) & ~3) + 16 * 9 * 32 + 8 * 32);
         if (part) { if ((rc = opt_in_lds(conv3x3_fwd_kernel<16, 32, true>, lds))) return rc;
                     SHM_LAUNCH((conv3x3_fwd_kernel<16, 32, true>), dim3(B), dim3(256), lds, s, x, w, bias, y, part, H, W); }
         else { if ((rc = opt_in_lds(conv3x3_fwd_kernel<16, 32, false>, lds))) return rc;
