@@ -221,6 +221,99 @@ __global__ void __launch_bounds__(256) linear_bwd_dx_kernel(int B, int F, int O,
     dx[i] = acc;
 }
 
+// The two dense products above on the matrix pipe, exact fp32 (v_mfma_f32_16x16x4_f32), for layers at least 16 wide.
+// Forward: one workgroup = one 16 x 16 output tile, its four waves split K = F (both operands are K-contiguous rows, so a lane's four
+// k-steps are one 16-byte global read each for the input row and the weight row — no LDS staging), accumulators added in wave order,
+// then the same epilogue as linear_fwd_kernel.  Requires F % 16 == 0.
+__global__ void __launch_bounds__(256) linear_fwd_mfma_kernel(int B, int F, int O, const float* __restrict__ in, const float* __restrict__ Wt,
+                                                              const float* __restrict__ bias, float* __restrict__ pre, float* __restrict__ out,
+                                                              int relu, float drop_p, unsigned long long drop_seed) {
+    __shared__ __attribute__((aligned(16))) float red[4][256];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
+    const int o0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+    const int kblocks = F / 16, per = (kblocks + 3) / 4, k0 = wave * per, k1 = min(kblocks, k0 + per);
+    const float* arow = in + (size_t)min(b0 + j, B - 1) * F + 4 * q;           // rows past the batch / the layer shadow the last valid one
+    const float* wrow = Wt + (size_t)min(o0 + j, O - 1) * F + 4 * q;           // and are dropped in the epilogue
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // four k-blocks of operands in flight (a rotating register ring; loads past the range re-read the last block and are not used)
+    constexpr int PF = 4;
+    f32x4 ar[PF], wr[PF];
+    const int klast = max(k1 - 1, k0);
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int kk = min(k0 + u, klast);
+        ar[u] = *reinterpret_cast<const f32x4*>(arow + kk * 16); wr[u] = *reinterpret_cast<const f32x4*>(wrow + kk * 16);
+    }
+    for (int kb = k0; kb < k1; kb += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            if (kb + u < k1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = mfma_f32_16x16x4(ar[u][e], wr[u][e], acc);
+            }
+            const int kk = min(kb + u + PF, klast);
+            ar[u] = *reinterpret_cast<const f32x4*>(arow + kk * 16); wr[u] = *reinterpret_cast<const f32x4*>(wrow + kk * 16);
+        }
+    }
+    *reinterpret_cast<f32x4*>(&red[wave][lane * 4]) = acc;    // accumulator (q, j), r  <->  row 4q + r (batch), column j (output)
+    __syncthreads();
+    {
+        const int l = tid >> 2, r = tid & 3, b = b0 + 4 * (l >> 4) + r, o = o0 + (l & 15);
+        if (b < B && o < O) {
+            float v = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) + bias[o];
+            if (pre) pre[(size_t)b * O + o] = v;
+            if (relu) v = fmaxf(v, 0.f);
+            if (drop_p > 0.f) v = drop_hash(drop_seed, 2u, (uint32_t)(b * O + o)) >= drop_threshold(drop_p) ? v * (1.0f / (1.0f - drop_p)) : 0.f;
+            out[(size_t)b * O + o] = v;
+        }
+    }
+}
+// Backward data: dx[b][f] = sum_o dy[b][o] W[o][f].  A wave = one 16 (batch) x 16 (f) tile, K = O: dy rows are K-contiguous (16-byte reads),
+// the weight operand is four 4-byte reads per k-block (rows o, 16 consecutive f per quarter-wave).  Requires O % 16 == 0.
+__global__ void __launch_bounds__(256) linear_bwd_dx_mfma_kernel(int B, int F, int O, const float* __restrict__ dy, const float* __restrict__ Wt,
+                                                                 const float* __restrict__ pre, float* __restrict__ dx, float drop_p,
+                                                                 unsigned long long drop_seed) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
+    const int f0 = (blockIdx.x * 4 + wave) * 16, b0 = blockIdx.y * 16;
+    if (f0 >= F) return;
+    const float* arow = dy + (size_t)min(b0 + j, B - 1) * O + 4 * q;
+    const float* wcol = Wt + (size_t)(4 * q) * F + min(f0 + j, F - 1);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    constexpr int PF = 4;                                     // k-blocks of operands in flight (see linear_fwd_mfma_kernel)
+    f32x4 ar[PF], wr[PF];
+    const int nkb = O / 16;
+    auto fetch = [&](int u, int kb) {
+        const int kk = min(kb, nkb - 1);
+        ar[u] = *reinterpret_cast<const f32x4*>(arow + kk * 16);
+        const float* wp = wcol + (size_t)kk * 16 * F;
+        wr[u][0] = wp[0]; wr[u][1] = wp[F]; wr[u][2] = wp[2 * (size_t)F]; wr[u][3] = wp[3 * (size_t)F];
+    };
+#pragma unroll
+    for (int u = 0; u < PF; ++u) fetch(u, u);
+    for (int kb = 0; kb < nkb; kb += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            if (kb + u < nkb) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = mfma_f32_16x16x4(ar[u][e], wr[u][e], acc);
+            }
+            fetch(u, kb + u + PF);
+        }
+    }
+    const int f = f0 + j;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int b = b0 + 4 * q + r;
+        if (b < B && f < F) {
+            const size_t i = (size_t)b * F + f;
+            float v = acc[r];
+            if (drop_p > 0.f) v = drop_hash(drop_seed, 2u, (uint32_t)i) >= drop_threshold(drop_p) ? v / (1.0f - drop_p) : 0.f;
+            if (pre) v = pre[i] > 0.f ? v : 0.f;
+            dx[i] = v;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ cross-entropy
 // one block: loss = mean_b -log softmax(logits)[y_b]; dlogits = (softmax - onehot) / B    (nn.CrossEntropyLoss())
 __global__ void __launch_bounds__(256) ce_loss_kernel(int B, int NC, const float* __restrict__ logits, const long long* __restrict__ labels,
@@ -582,14 +675,22 @@ int cnn_bn_relu_pool(int B, int C, int H, int W, const float* y, const float* sc
 }
 int cnn_linear_fwd(int B, int F, int O, const float* in, const float* Wt, const float* bias, float* pre, float* out, int relu, float drop_p,
                    uint64_t seed, hipStream_t s) {
-    SHM_LAUNCH(linear_fwd_kernel, dim3(ceil_div(O, 32), ceil_div(B, 8)), dim3(256), 0, s, B, F, O, in, Wt, bias, pre, out, relu, drop_p,
-                       (unsigned long long)seed);
+    const bool aligned = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(Wt)) & 15) == 0;
+    if (O >= 16 && F % 16 == 0 && aligned && !getenv("SHM_CNN_VALU_DENSE"))
+        SHM_LAUNCH(linear_fwd_mfma_kernel, dim3(ceil_div(O, 16), ceil_div(B, 16)), dim3(256), 0, s, B, F, O, in, Wt, bias, pre, out, relu, drop_p,
+                   (unsigned long long)seed);
+    else
+        SHM_LAUNCH(linear_fwd_kernel, dim3(ceil_div(O, 32), ceil_div(B, 8)), dim3(256), 0, s, B, F, O, in, Wt, bias, pre, out, relu, drop_p,
+                   (unsigned long long)seed);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
 int cnn_linear_bwd_dx(int B, int F, int O, const float* dy, const float* Wt, const float* pre, float* dx, float drop_p, uint64_t seed, hipStream_t s) {
     const size_t n = (size_t)B * F;
-    SHM_LAUNCH(linear_bwd_dx_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, B, F, O, dy, Wt, pre, dx, drop_p, (unsigned long long)seed);
+    if (O >= 16 && O % 16 == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0 && !getenv("SHM_CNN_VALU_DENSE"))
+        SHM_LAUNCH(linear_bwd_dx_mfma_kernel, dim3(ceil_div(F, 64), ceil_div(B, 16)), dim3(256), 0, s, B, F, O, dy, Wt, pre, dx, drop_p, (unsigned long long)seed);
+    else
+        SHM_LAUNCH(linear_bwd_dx_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, B, F, O, dy, Wt, pre, dx, drop_p, (unsigned long long)seed);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
