@@ -402,17 +402,19 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(int C, int H, int W, 
                                                            const float* __restrict__ gamma, const float* __restrict__ k1, const float* __restrict__ k2,
                                                            float* __restrict__ dy) {
     const int Hp = H / 2, Wp = W / 2, b = blockIdx.x, HW = H * W;
-    for (int e = threadIdx.x; e < C * HW; e += 256) {
-        const int c = e / HW, r = e - c * HW, h = r / W, w = r - h * W;
-        const int hp = h >> 1, wp = w >> 1;
-        float da = 0.f;
-        if (hp < Hp && wp < Wp) {
-            const size_t pe = ((size_t)b * C + c) * Hp * Wp + (size_t)hp * Wp + wp;
-            if (idx[pe] == ((h & 1) * 2 + (w & 1))) da = dp[pe];
+    for (int c = 0; c < C; ++c) {                              // per-channel constants once per channel, one division per element
+        const float m = mean[c], rs = rstd[c], sc = gamma[c] * rstd[c], c1 = k1[c], c2 = k2[c];
+        const size_t cb = ((size_t)b * C + c) * HW, pb = ((size_t)b * C + c) * Hp * Wp;
+        for (int r = threadIdx.x; r < HW; r += 256) {
+            const int h = r / W, w = r - h * W, hp = h >> 1, wp = w >> 1;
+            float da = 0.f;
+            if (hp < Hp && wp < Wp) {
+                const size_t pe = pb + (size_t)hp * Wp + wp;
+                if (idx[pe] == ((h & 1) * 2 + (w & 1))) da = dp[pe];
+            }
+            const float xh = (y[cb + r] - m) * rs;
+            dy[cb + r] = sc * (da - c1 - xh * c2);
         }
-        const size_t o = (size_t)b * C * HW + e;
-        const float xh = (y[o] - mean[c]) * rstd[c];
-        dy[o] = gamma[c] * rstd[c] * (da - k1[c] - xh * k2[c]);
     }
 }
 
@@ -526,26 +528,23 @@ __global__ void __launch_bounds__(256) conv3x3_bwd_weight_kernel(const float* __
 
 // The same per-window partial on the matrix pipe, exact fp32 (v_mfma_f32_16x16x4_f32): part[co][n] = sum_p dy[co][p] * col[p][n] with
 // n = ci * 9 + tap and col = the im2col view of x (never materialised): M = 16 output channels, N = 16 (ci, tap) columns, K = positions.
-// dy sits in LDS position-fastest (row stride K + 4: the 16 rows of a fragment land on different banks), so a lane's four k-steps
-// are one 16-byte read; x sits in LDS with a zero halo and a per-position offset table, so a column value is one 4-byte read at
-// table[p] + (ci, tap offset).  With >= 8 output tiles (conv2: 2 x 9) the waves take different tiles; otherwise (conv1: 1 x 2) they
-// split the positions and their accumulators are added in wave order.  Bias gradient: the vector loop of the kernel above.
+// dy rows are position-contiguous, so a lane's four k-steps are ONE 16-byte global read (a rotating register ring keeps four
+// k-blocks in flight; no LDS copy of dy); x sits in LDS with a zero halo and a per-position offset table, so a column value is one
+// 4-byte LDS read at table[p] + (ci, tap offset).  With >= 8 output tiles (conv2: 2 x 9) the waves take different tiles; otherwise
+// (conv1: 1 x 2) they split the positions and their accumulators are added in wave order.  The bias gradient (row sums of dy) falls
+// out of the A fragments: every lane adds its four values per k-block, the four lane quarters are combined by shuffles.
+// Requires H * W % 4 == 0 (16-byte reads of dy rows).
 template <int CIN, int COUT>
 __global__ void __launch_bounds__(512) conv3x3_bwd_weight_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                       float* __restrict__ part, int H, int W) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    constexpr int NCOL = CIN * 9, MT = COUT / 16, NT = (NCOL + 15) / 16, NWV = 8, NW_ = COUT * NCOL;
+    constexpr int NCOL = CIN * 9, MT = COUT / 16, NT = (NCOL + 15) / 16, NWV = 8, NW_ = COUT * NCOL, PF = 4;
     constexpr bool TILE_PAR = MT * NT >= NWV;
-    const int HW = H * W, KP = (HW + 15) & ~15, DS = KP + 4, WP = W + 2, XP = (H + 2) * WP, XPP = (CIN * XP + 3) & ~3;
+    const int HW = H * W, KP = (HW + 15) & ~15, NKB = KP / 16, WP = W + 2, XP = (H + 2) * WP, XPP = (CIN * XP + 3) & ~3;
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
-    float* ds = sm;                                           // [COUT][DS], zero beyond HW
-    float* xs = ds + COUT * DS;                               // [CIN][H + 2][W + 2], zero halo
+    float* xs = sm;                                           // [CIN][H + 2][W + 2], zero halo
     int* posoff = reinterpret_cast<int*>(xs + XPP);           // [KP]: (h + 1) * WP + (w + 1) of position p
-    float* red = reinterpret_cast<float*>(posoff + KP);       // position-split only: [NWV][MT * NT][256]
-    for (int e = tid; e < COUT * KP; e += 512) {
-        const int co = e / KP, p = e - co * KP;
-        ds[co * DS + p] = p < HW ? dy[((size_t)b * COUT + co) * HW + p] : 0.f;
-    }
+    float* red = reinterpret_cast<float*>(posoff + KP);       // position-split only: [NWV][MT * NT][256] accumulators | [NWV][COUT] row sums
     for (int e = tid; e < CIN * XP; e += 512) {
         const int ci = e / XP, r = e - ci * XP, hh = r / WP - 1, ww = r - (hh + 1) * WP - 1;
         xs[e] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? x[((size_t)b * CIN + ci) * HW + hh * W + ww] : 0.f;
@@ -553,11 +552,17 @@ __global__ void __launch_bounds__(512) conv3x3_bwd_weight_mfma_kernel(const floa
     for (int p = tid; p < KP; p += 512) posoff[p] = p < HW ? (p / W + 1) * WP + (p % W + 1) : WP + 1;   // padding: any valid cell (dy is 0 there)
     __syncthreads();
     float* out = part + (size_t)b * (NW_ + COUT);
+    const float* dyb = dy + (size_t)b * COUT * HW;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     auto column = [&](int nt, int& boff, float& keep) {       // this lane's column n = nt * 16 + j of the im2col view
         const int n = nt * 16 + j, ok = n < NCOL, nn = ok ? n : 0, ci = nn / 9, tap = nn - ci * 9;
         boff = ci * XP + (tap / 3 - 1) * WP + (tap % 3 - 1);
         keep = ok ? 1.f : 0.f;
+    };
+    auto a_load = [&](const float* arow, int kb) -> f32x4 {   // positions kb*16 + 4q .. +3 of this lane's dy row (zero past the window)
+        const int kk = kb < NKB ? kb : NKB - 1, p = kk * 16 + 4 * q;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(arow + (p < HW ? p : 0));
+        return p < HW ? v : zero4;
     };
     if constexpr (TILE_PAR) {
         constexpr int G = NWV / MT, NTW = (NT + G - 1) / G;
@@ -565,20 +570,32 @@ __global__ void __launch_bounds__(512) conv3x3_bwd_weight_mfma_kernel(const floa
         int boff[NTW]; float keep[NTW]; f32x4 acc[NTW];
 #pragma unroll
         for (int i = 0; i < NTW; ++i) { column(nt0 + (i < ntn ? i : 0), boff[i], keep[i]); acc[i] = zero4; }
-        const float* arow = ds + (mt * 16 + j) * DS + 4 * q;
-        for (int kb = 0; kb < KP / 16; ++kb) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(arow + kb * 16);
-            const int* pp = posoff + kb * 16 + 4 * q;
-            const int p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3];
+        const float* arow = dyb + (size_t)(mt * 16 + j) * HW;
+        f32x4 ar[PF];
 #pragma unroll
-            for (int i = 0; i < NTW; ++i)
-                if (i < ntn) {
-                    const float* xb = xs + boff[i];
-                    acc[i] = mfma_f32_16x16x4(a[0], xb[p0] * keep[i], acc[i]);
-                    acc[i] = mfma_f32_16x16x4(a[1], xb[p1] * keep[i], acc[i]);
-                    acc[i] = mfma_f32_16x16x4(a[2], xb[p2] * keep[i], acc[i]);
-                    acc[i] = mfma_f32_16x16x4(a[3], xb[p3] * keep[i], acc[i]);
+        for (int u = 0; u < PF; ++u) ar[u] = a_load(arow, u);
+        float bsum = 0.f;
+        for (int kb0 = 0; kb0 < NKB; kb0 += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int kb = kb0 + u;
+                if (kb < NKB) {
+                    const f32x4 a = ar[u];
+                    bsum += (a[0] + a[1]) + (a[2] + a[3]);
+                    const int* pp = posoff + kb * 16 + 4 * q;
+                    const int p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3];
+#pragma unroll
+                    for (int i = 0; i < NTW; ++i)
+                        if (i < ntn) {
+                            const float* xb = xs + boff[i];
+                            acc[i] = mfma_f32_16x16x4(a[0], xb[p0] * keep[i], acc[i]);
+                            acc[i] = mfma_f32_16x16x4(a[1], xb[p1] * keep[i], acc[i]);
+                            acc[i] = mfma_f32_16x16x4(a[2], xb[p2] * keep[i], acc[i]);
+                            acc[i] = mfma_f32_16x16x4(a[3], xb[p3] * keep[i], acc[i]);
+                        }
                 }
+                ar[u] = a_load(arow, kb + PF);
+            }
         }
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
@@ -588,33 +605,60 @@ __global__ void __launch_bounds__(512) conv3x3_bwd_weight_mfma_kernel(const floa
                 for (int r = 0; r < 4; ++r) out[(size_t)(mt * 16 + 4 * q + r) * NCOL + n] = acc[i][r];
             }
         }
+        bsum += __shfl_xor(bsum, 16, 64); bsum += __shfl_xor(bsum, 32, 64);
+        if (g == 0 && q == 0) out[NW_ + mt * 16 + j] = bsum;            // bias gradient of this window
     } else {
         constexpr int TILES = MT * NT;
         int boff[NT]; float keep[NT]; f32x4 acc[TILES];
+        float bsum[MT];
 #pragma unroll
         for (int i = 0; i < NT; ++i) column(i, boff[i], keep[i]);
 #pragma unroll
         for (int i = 0; i < TILES; ++i) acc[i] = zero4;
-        for (int kb = wave; kb < KP / 16; kb += NWV) {
-            const int* pp = posoff + kb * 16 + 4 * q;
-            const int p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3];
-            float bv[NT][4];
 #pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                const float* xb = xs + boff[i];
-                bv[i][0] = xb[p0] * keep[i]; bv[i][1] = xb[p1] * keep[i]; bv[i][2] = xb[p2] * keep[i]; bv[i][3] = xb[p3] * keep[i];
-            }
+        for (int m = 0; m < MT; ++m) bsum[m] = 0.f;
+        // wave w takes k-blocks w, w + 8, ...; the ring holds the next PF of them
+        f32x4 ar[PF][MT];
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(ds + (m * 16 + j) * DS + kb * 16 + 4 * q);
+        for (int u = 0; u < PF; ++u)
 #pragma unroll
-                for (int i = 0; i < NT; ++i)
+            for (int m = 0; m < MT; ++m) ar[u][m] = a_load(dyb + (size_t)(m * 16 + j) * HW, wave + u * NWV);
+        for (int kb0 = wave; kb0 < NKB; kb0 += PF * NWV) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[m * NT + i] = mfma_f32_16x16x4(a[e], bv[i][e], acc[m * NT + i]);
+            for (int u = 0; u < PF; ++u) {
+                const int kb = kb0 + u * NWV;
+                if (kb < NKB) {
+                    const int* pp = posoff + kb * 16 + 4 * q;
+                    const int p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3];
+                    float bv[NT][4];
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) {
+                        const float* xb = xs + boff[i];
+                        bv[i][0] = xb[p0] * keep[i]; bv[i][1] = xb[p1] * keep[i]; bv[i][2] = xb[p2] * keep[i]; bv[i][3] = xb[p3] * keep[i];
+                    }
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        const f32x4 a = ar[u][m];
+                        bsum[m] += (a[0] + a[1]) + (a[2] + a[3]);
+#pragma unroll
+                        for (int i = 0; i < NT; ++i)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[m * NT + i] = mfma_f32_16x16x4(a[e], bv[i][e], acc[m * NT + i]);
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < MT; ++m) ar[u][m] = a_load(dyb + (size_t)(m * 16 + j) * HW, kb + PF * NWV);
             }
         }
+        float* redb = red + (size_t)NWV * TILES * 256;          // [NWV][COUT]
 #pragma unroll
         for (int i = 0; i < TILES; ++i) *reinterpret_cast<f32x4*>(red + ((size_t)(wave * TILES + i) * 64 + lane) * 4) = acc[i];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            float v = bsum[m];
+            v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+            if (q == 0) redb[wave * COUT + m * 16 + j] = v;
+        }
         __syncthreads();
         for (int e = tid; e < TILES * 256; e += 512) {
             const int tile = e >> 8, l = (e & 255) >> 2, r = e & 3, m = tile / NT, nt = tile - m * NT;
@@ -624,12 +668,12 @@ __global__ void __launch_bounds__(512) conv3x3_bwd_weight_mfma_kernel(const floa
             for (int w = 0; w < NWV; ++w) v += red[(size_t)(w * TILES + tile) * 256 + (e & 255)];
             if (n < NCOL) out[(size_t)(m * 16 + 4 * (l >> 4) + r) * NCOL + n] = v;
         }
-    }
-    for (int e = tid; e < COUT; e += 512) {                   // bias gradient of this window
-        const float* dr = ds + e * DS;
-        float acc = 0.f;
-        for (int p = 0; p < HW; ++p) acc += dr[p];
-        out[NW_ + e] = acc;
+        for (int e = tid; e < COUT; e += 512) {                  // bias gradient of this window
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWV; ++w) v += redb[w * COUT + e];
+            out[NW_ + e] = v;
+        }
     }
 }
 
@@ -733,8 +777,8 @@ int cnn_conv_bwd_weight(int layer, int B, int H, int W, const float* dy, const f
     // matrix-pipe version unless its staged window does not fit the LDS (or SHM_CNN_VALU_WGRAD is set: measurement knob)
     const int HW = H * W, KP = (HW + 15) & ~15, XP = (H + 2) * (W + 2);
     const int cin = layer == 1 ? 2 : 16, cout = layer == 1 ? 16 : 32, tiles = (cout / 16) * ((cin * 9 + 15) / 16);
-    const size_t lds_m = sizeof(float) * ((size_t)cout * (KP + 4) + ((cin * XP + 3) & ~3) + KP + (tiles >= 8 ? 0 : (size_t)8 * tiles * 256));
-    if (lds_m <= 150 * 1024 && !getenv("SHM_CNN_VALU_WGRAD")) {
+    const size_t lds_m = sizeof(float) * ((size_t)((cin * XP + 3) & ~3) + KP + (tiles >= 8 ? 0 : (size_t)8 * tiles * 256 + 8 * cout));
+    if (lds_m <= 150 * 1024 && HW % 4 == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0 && !getenv("SHM_CNN_VALU_WGRAD")) {
         if (layer == 1) {
             if ((rc = opt_in_lds(conv3x3_bwd_weight_mfma_kernel<2, 16>, lds_m))) return rc;
             SHM_LAUNCH((conv3x3_bwd_weight_mfma_kernel<2, 16>), dim3(B), dim3(512), lds_m, s, dy, x, part, H, W);
