@@ -95,6 +95,94 @@ __global__ void __launch_bounds__(256) conv3x3_fwd_kernel(const float* __restric
     }
 }
 
+// The same convolution on the matrix pipe, exact fp32 (v_mfma_f32_16x16x4_f32): y[co][p] = b[co] + sum_k W[co][k] col[k][p] with k = ci * 9 + tap
+// in the weights' own order (no re-layout) and col = the im2col view of x (never materialised): M = 16 output channels, N = 16
+// consecutive positions, K = CIN * 9 padded to a multiple of 4.  The A fragments of a wave (all of W it needs: KS values per M-tile)
+// live in registers for the whole window; a B value is one 4-byte LDS read out of the halo-padded x at (position offset + k offset).
+// grid = B, block = 512 (8 waves, position tiles dealt round-robin).  STATS: per-channel sum / sum of squares of this window,
+// lane-local over the wave's tiles, combined by shuffles, one barrier, then a fixed-order sum over the waves.
+template <int CIN, int COUT, bool STATS>
+__global__ void __launch_bounds__(512) conv3x3_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, float* __restrict__ y,
+                                                               float* __restrict__ part, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int NK = CIN * 9, KS = (NK + 3) / 4, MT = COUT / 16, NWV = 8;
+    const int HW = H * W, WP = W + 2, XP = (H + 2) * WP, ntiles = (HW + 15) / 16;
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
+    float* xs = sm;                                           // [CIN][H + 2][W + 2], zero halo
+    float* red = sm + ((CIN * XP + 3) & ~3);                  // STATS: [NWV][COUT][2]
+    // eight loads in flight per thread: issued one per trip, every global read would wait out its full latency before the next
+    for (int e0 = tid; e0 < CIN * XP; e0 += 512 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * 512, ec = e < CIN * XP ? e : 0;
+            const int ci = ec / XP, r = ec - ci * XP, hh = r / WP - 1, ww = r - (hh + 1) * WP - 1;
+            v[u] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? x[((size_t)b * CIN + ci) * HW + hh * W + ww] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (e0 + u * 512 < CIN * XP) xs[e0 + u * 512] = v[u];
+    }
+    // A: lane (q, j) holds W[m * 16 + j][4 s + q]; B offsets: k = 4 s + q -> (ci, tap) -> ci * XP + dh * WP + dw
+    float a[MT][KS];
+    int koff[KS];
+#pragma unroll
+    for (int s2 = 0; s2 < KS; ++s2) {
+        const int k = 4 * s2 + q, ok = k < NK, kk = ok ? k : 0, ci = kk / 9, tap = kk - ci * 9;
+        koff[s2] = ci * XP + (tap / 3 - 1) * WP + (tap % 3 - 1);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a[m][s2] = ok ? w[(size_t)(m * 16 + j) * NK + k] : 0.f;      // zero weight: the padded k contributes nothing
+    }
+    float bia[MT][4], s1[MT][4], s2v[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { bia[m][r] = bias[m * 16 + 4 * q + r]; s1[m][r] = 0.f; s2v[m][r] = 0.f; }
+    __syncthreads();
+    for (int nt = wave; nt < ntiles; nt += NWV) {
+        const int p = nt * 16 + j, pc = p < HW ? p : HW - 1, h = pc / W, ww = pc - h * W;
+        const float* xb = xs + (h + 1) * WP + (ww + 1);
+        f32x4 acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = f32x4{bia[m][0], bia[m][1], bia[m][2], bia[m][3]};
+#pragma unroll
+        for (int s3 = 0; s3 < KS; ++s3) {
+            const float bv = xb[koff[s3]];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = mfma_f32_16x16x4(a[m][s3], bv, acc[m]);
+        }
+        if (p < HW) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = acc[m][r];
+                    y[((size_t)b * COUT + m * 16 + 4 * q + r) * HW + p] = v;
+                    if (STATS) { s1[m][r] += v; s2v[m][r] = fmaf(v, v, s2v[m][r]); }
+                }
+        }
+    }
+    if (STATS) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float u = s1[m][r], v = s2v[m][r];
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) { u += __shfl_xor(u, off, 64); v += __shfl_xor(v, off, 64); }
+                if (j == 0) { red[(wave * COUT + m * 16 + 4 * q + r) * 2] = u; red[(wave * COUT + m * 16 + 4 * q + r) * 2 + 1] = v; }
+            }
+        __syncthreads();
+        for (int e = tid; e < 2 * COUT; e += 512) {
+            float v = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < NWV; ++wv) v += red[wv * COUT * 2 + e];
+            part[(size_t)b * COUT * 2 + e] = v;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ BatchNorm statistics
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
@@ -545,9 +633,18 @@ __global__ void __launch_bounds__(512) conv3x3_bwd_weight_mfma_kernel(const floa
     float* xs = sm;                                           // [CIN][H + 2][W + 2], zero halo
     int* posoff = reinterpret_cast<int*>(xs + XPP);           // [KP]: (h + 1) * WP + (w + 1) of position p
     float* red = reinterpret_cast<float*>(posoff + KP);       // position-split only: [NWV][MT * NT][256] accumulators | [NWV][COUT] row sums
-    for (int e = tid; e < CIN * XP; e += 512) {
-        const int ci = e / XP, r = e - ci * XP, hh = r / WP - 1, ww = r - (hh + 1) * WP - 1;
-        xs[e] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? x[((size_t)b * CIN + ci) * HW + hh * W + ww] : 0.f;
+    // eight loads in flight per thread: issued one per trip, every global read would wait out its full latency before the next
+    for (int e0 = tid; e0 < CIN * XP; e0 += 512 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * 512, ec = e < CIN * XP ? e : 0;
+            const int ci = ec / XP, r = ec - ci * XP, hh = r / WP - 1, ww = r - (hh + 1) * WP - 1;
+            v[u] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? x[((size_t)b * CIN + ci) * HW + hh * W + ww] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (e0 + u * 512 < CIN * XP) xs[e0 + u * 512] = v[u];
     }
     for (int p = tid; p < KP; p += 512) posoff[p] = p < HW ? (p / W + 1) * WP + (p % W + 1) : WP + 1;   // padding: any valid cell (dy is 0 there)
     __syncthreads();
@@ -687,9 +784,28 @@ int opt_in_lds(K kern, size_t lds) {
 }  // namespace
 
 // =================================================================================================== launchers
+template <int CIN, int COUT>
+int conv_fwd_mfma(int B, int H, int W, const float* x, const float* w, const float* bias, float* y, float* part, hipStream_t s) {
+    const size_t lds = sizeof(float) * ((size_t)((CIN * (H + 2) * (W + 2) + 3) & ~3) + 8 * COUT * 2);
+    int rc;
+    if (part) { if ((rc = opt_in_lds(conv3x3_fwd_mfma_kernel<CIN, COUT, true>, lds))) return rc;
+                SHM_LAUNCH((conv3x3_fwd_mfma_kernel<CIN, COUT, true>), dim3(B), dim3(512), lds, s, x, w, bias, y, part, H, W); }
+    else { if ((rc = opt_in_lds(conv3x3_fwd_mfma_kernel<CIN, COUT, false>, lds))) return rc;
+           SHM_LAUNCH((conv3x3_fwd_mfma_kernel<CIN, COUT, false>), dim3(B), dim3(512), lds, s, x, w, bias, y, part, H, W); }
+    SHM_LAUNCH_CHECK();
+    return SHM_OK;
+}
 int cnn_conv_fwd(int layer, int B, int H, int W, const float* x, const float* w, const float* bias, float* y, float* part, hipStream_t s) {
     const int HW = H * W;
     int rc;
+    // conv1 (2 -> 16 channels, memory-bound) runs on the matrix pipe: 16 vs 29 us at the north-star shape.  conv2 as the same kernel
+    // holds one 8-wave workgroup per CU (187 VGPRs): with at most one workgroup per CU (B <= 256, e.g. the reference's 100-window
+    // batches) it beats the vector kernel below (eval 0.071 vs 0.088 ms), with two rounds (B = 512) it measured 61 us against 41 us,
+    // so larger batches stay on the vector path.  SHM_CNN_VALU_CONV / SHM_CNN_MFMA_CONV2: measurement knobs.
+    if (!getenv("SHM_CNN_VALU_CONV")) {
+        if (layer == 1) return conv_fwd_mfma<2, 16>(B, H, W, x, w, bias, y, part, s);
+        if (B <= 256 || getenv("SHM_CNN_MFMA_CONV2")) return conv_fwd_mfma<16, 32>(B, H, W, x, w, bias, y, part, s);
+    }
     if (layer == 1) {
         const size_t lds = sizeof(float) * (((2 * HW + 3) & ~3) + 2 * 9 * 16 + 8 * 16);
         if (part) { if ((rc = opt_in_lds(conv3x3_fwd_kernel<2, 16, true>, lds))) return rc;

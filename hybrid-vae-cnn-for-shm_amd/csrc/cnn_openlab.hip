@@ -70,9 +70,21 @@ __device__ __forceinline__ void ol_conv_mfma(const float* __restrict__ xin, cons
         __syncthreads();                                              // the previous chunk's reads are done
         // staged rows hc0 - PT .. hc0 + hc + PT - 1 (zero outside the window), all W columns, channel-fastest; no column halo: a tap
         // that leaves the row is masked at the read
-        for (int e = tid; e < CIN * rows * W; e += OL_THREADS) {      // global reads walk (row, column) of one channel plane
-            const int ci = e / (rows * W), rem = e - ci * rows * W, hh = hc0 - PT + rem / W;
-            xs[rem * CINP + ci] = (hh >= 0 && hh < H) ? xin[(size_t)ci * HW + (size_t)(hc0 - PT) * W + rem] : 0.f;
+        // global reads walk (row, column) of one channel plane; eight loads in flight per thread (issued one per trip, every read
+        // would wait out its full latency before the next)
+        for (int e0 = tid; e0 < CIN * rows * W; e0 += OL_THREADS * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * OL_THREADS, ec = e < CIN * rows * W ? e : 0;
+                const int ci = ec / (rows * W), rem = ec - ci * rows * W, hh = hc0 - PT + rem / W;
+                v[u] = (hh >= 0 && hh < H) ? xin[(size_t)ci * HW + (size_t)(hc0 - PT) * W + rem] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * OL_THREADS;
+                if (e < CIN * rows * W) { const int ci = e / (rows * W), rem = e - ci * rows * W; xs[rem * CINP + ci] = v[u]; }
+            }
         }
         __syncthreads();
         const int npos = hc * W, ntiles = (npos + 15) / 16, ngroups = (ntiles + OL_NTW - 1) / OL_NTW, mtiles = COUT / 16;
