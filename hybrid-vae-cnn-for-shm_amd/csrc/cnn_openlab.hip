@@ -218,7 +218,15 @@ __global__ void __launch_bounds__(OL_THREADS, 4) ol_block_kernel(const float* __
         for (int g = wv; g < wv + 1; ++g) {
             const float* yg = yb + (size_t)g * n;
             double s = 0.0, q = 0.0;
-            for (int i = lane; i < n; i += 64) { const double v = (double)yg[i]; s += v; q += v * v; }
+            int i = lane;
+            for (; i + 7 * 64 < n; i += 8 * 64) {            // eight loads in flight; the sums keep their lane-sequential order
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = yg[i + u * 64];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const double d = (double)v[u]; s += d; q += d * d; }
+            }
+            for (; i < n; i += 64) { const double v = (double)yg[i]; s += v; q += v * v; }
             s = wave_sum_f64(s); q = wave_sum_f64(q);
             if (lane == 0) {
                 const double m = s / n;
@@ -235,12 +243,22 @@ __global__ void __launch_bounds__(OL_THREADS, 4) ol_block_kernel(const float* __
     if constexpr (!LAST) {
         const int Hp = H / 2;
         float* ob = out + (size_t)b * COUT * Hp * W;
-        for (int e = tid; e < COUT * Hp * W; e += OL_THREADS) {
-            const int co = e / (Hp * W), r = e - co * Hp * W, hp = r / W, w0 = r - hp * W, g = co / cg;
-            const float sc = gamma[co] * g_rstd[g], sh = beta[co] - g_mean[g] * sc;
-            const float v0 = silu(fmaf(yb[(size_t)co * HW + (2 * hp) * W + w0], sc, sh));
-            const float v1 = silu(fmaf(yb[(size_t)co * HW + (2 * hp + 1) * W + w0], sc, sh));
-            ob[e] = fmaxf(v0, v1);
+        const int nout = COUT * Hp * W;
+        for (int e0 = tid; e0 < nout; e0 += OL_THREADS * 4) {        // the eight reads of four outputs are issued together
+            float a0[4], a1[4], sc[4], sh[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = min(e0 + u * OL_THREADS, nout - 1);
+                const int co = e / (Hp * W), r = e - co * Hp * W, hp = r / W, w0 = r - hp * W, g = co / cg;
+                sc[u] = gamma[co] * g_rstd[g]; sh[u] = beta[co] - g_mean[g] * sc[u];
+                a0[u] = yb[(size_t)co * HW + (2 * hp) * W + w0];
+                a1[u] = yb[(size_t)co * HW + (2 * hp + 1) * W + w0];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * OL_THREADS;
+                if (e < nout) ob[e] = fmaxf(silu(fmaf(a0[u], sc[u], sh[u])), silu(fmaf(a1[u], sc[u], sh[u])));
+            }
         }
     } else {
         // AdaptiveAvgPool(1,1): OL_THREADS / 256 threads per channel (COUT == 256), each over a contiguous share of the positions; fixed order
