@@ -27,6 +27,19 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// Staging loops (global -> LDS): U loads in flight per thread.  Written as "dst[i] = src[i]" per trip, every global read waits out its
+// whole latency before the next one is issued — a 32-trip staging loop was most of a 30 us kernel.
+template <int NTHR, int U = 8, typename LoadF, typename StoreF>
+__device__ __forceinline__ void stage_elems(int n, int tid, LoadF load, StoreF store) {
+    for (int e0 = tid; e0 < n; e0 += NTHR * U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int e = e0 + u * NTHR; v[u] = load(e < n ? e : 0); }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int e = e0 + u * NTHR; if (e < n) store(e, v[u]); }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ conv forward
 // grid = B, block = 256.  LDS: x[CIN][H*W] | w[(ci*9+k)][COUT] | red[4 waves][COUT][2]
 template <int CIN, int COUT, bool STATS>
@@ -38,11 +51,11 @@ __global__ void __launch_bounds__(256) conv3x3_fwd_kernel(const float* __restric
     float* xs = sm;
     float* ws = sm + ((CIN * HW + 3) & ~3);          // keep the weight rows 16-byte aligned for the float4 reads
     float* red = ws + CIN * 9 * COUT;
-    for (int e = tid; e < CIN * HW; e += 256) xs[e] = x[(size_t)b * CIN * HW + e];
-    for (int e = tid; e < COUT * CIN * 9; e += 256) {           // w[co][ci][k] -> ws[(ci*9+k)*COUT + co]
+    stage_elems<256>(CIN * HW, tid, [&](int e) { return x[(size_t)b * CIN * HW + e]; }, [&](int e, float v) { xs[e] = v; });
+    stage_elems<256>(COUT * CIN * 9, tid, [&](int e) { return w[e]; }, [&](int e, float v) {   // w[co][ci][k] -> ws[(ci*9+k)*COUT + co]
         const int co = e / (CIN * 9), r = e - co * CIN * 9;
-        ws[r * COUT + co] = w[e];
-    }
+        ws[r * COUT + co] = v;
+    });
     __syncthreads();
     float s1[COUT], s2[COUT];
     if (STATS) {
@@ -493,15 +506,28 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(int C, int H, int W, 
     for (int c = 0; c < C; ++c) {                              // per-channel constants once per channel, one division per element
         const float m = mean[c], rs = rstd[c], sc = gamma[c] * rstd[c], c1 = k1[c], c2 = k2[c];
         const size_t cb = ((size_t)b * C + c) * HW, pb = ((size_t)b * C + c) * Hp * Wp;
-        for (int r = threadIdx.x; r < HW; r += 256) {
-            const int h = r / W, w = r - h * W, hp = h >> 1, wp = w >> 1;
-            float da = 0.f;
-            if (hp < Hp && wp < Wp) {
-                const size_t pe = pb + (size_t)hp * Wp + wp;
-                if (idx[pe] == ((h & 1) * 2 + (w & 1))) da = dp[pe];
+        for (int r0 = threadIdx.x; r0 < HW; r0 += 4 * 256) {     // four elements per trip: their reads are issued together
+            float yv[4], dv[4];
+            int kk[4], sel[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = min(r0 + u * 256, HW - 1), h = r / W, w = r - h * W, hp = h >> 1, wp = w >> 1;
+                const bool in = hp < Hp && wp < Wp;
+                const size_t pe = pb + (in ? (size_t)hp * Wp + wp : 0);
+                yv[u] = y[cb + r];
+                kk[u] = in ? (int)idx[pe] : -1;
+                dv[u] = dp[pe];
+                sel[u] = (h & 1) * 2 + (w & 1);
             }
-            const float xh = (y[cb + r] - m) * rs;
-            dy[cb + r] = sc * (da - c1 - xh * c2);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = r0 + u * 256;
+                if (r < HW) {
+                    const float da = kk[u] == sel[u] ? dv[u] : 0.f;
+                    const float xh = (yv[u] - m) * rs;
+                    dy[cb + r] = sc * (da - c1 - xh * c2);
+                }
+            }
         }
     }
 }
@@ -515,11 +541,11 @@ __global__ void __launch_bounds__(256) conv3x3_bwd_data_kernel(const float* __re
     const int HW = H * W, b = blockIdx.x, tid = threadIdx.x;
     float* ds = sm;                          // [COUT][HW]
     float* ws = sm + COUT * HW;              // [(co*9+k)][CIN]
-    for (int e = tid; e < COUT * HW; e += 256) ds[e] = dy[(size_t)b * COUT * HW + e];
-    for (int e = tid; e < COUT * CIN * 9; e += 256) {           // w[co][ci][k] -> ws[(co*9+k)*CIN + ci]
+    stage_elems<256>(COUT * HW, tid, [&](int e) { return dy[(size_t)b * COUT * HW + e]; }, [&](int e, float v) { ds[e] = v; });
+    stage_elems<256>(COUT * CIN * 9, tid, [&](int e) { return w[e]; }, [&](int e, float v) {   // w[co][ci][k] -> ws[(co*9+k)*CIN + ci]
         const int co = e / (CIN * 9), r = e - co * CIN * 9, ci = r / 9, k = r - ci * 9;
-        ws[(co * 9 + k) * CIN + ci] = w[e];
-    }
+        ws[(co * 9 + k) * CIN + ci] = v;
+    });
     __syncthreads();
     for (int p = tid; p < HW; p += 256) {
         const int h = p / W, ww = p - h * W;
