@@ -101,6 +101,15 @@ class TemporalVAE(nn.Module):
         _, _, _, score, _, _ = eng.forward(x, eps, training_plan=False, train_mode=False, want_score=True, want_recon=False)
         return score
 
+    def score_and_reconstruct(self, x: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+        """(per-window MSE, reconstruction) of ONE eval forward (one epsilon draw): lets the hybrid gate hand the anomalous windows'
+        own reconstruction to the classifier instead of running the VAE a second time (the reference
+        draws twice, 06_test_full_pipeline.py:342,363)."""
+        eng = self._engine
+        eng.bind_parameters(dict(self.named_parameters()))
+        eps = torch.randn_like(torch.empty(x.size(0), self.latent_dim, dtype=torch.float32, device=x.device))
+        recon, _, _, score, _, _ = eng.forward(x, eps, training_plan=False, train_mode=False, want_score=True, want_recon=True)
+        return score, recon
 
 # Backward compatibility (if any old scripts still import VAE)
 VAE = TemporalVAE

@@ -22,13 +22,33 @@ def score_windows(vae, Z: torch.Tensor, batch: int = 512) -> torch.Tensor:
 
 
 @torch.no_grad()
-def hybrid_predict(vae, cnn, Z: torch.Tensor, threshold: float, batch: int = 512):
-    """Returns (mse [N], y_pred [N] in {0 normal, 1 sensor, 2 structural}, p_struct [N]) — 06_test_full_pipeline.py:339-372."""
+def hybrid_predict(vae, cnn, Z: torch.Tensor, threshold: float, batch: int = 512, reuse_recon: bool = False):
+    """Returns (mse [N], y_pred [N] in {0 normal, 1 sensor, 2 structural}, p_struct [N]) — 06_test_full_pipeline.py:339-372.
+
+    reuse_recon=False (default) is the reference's behaviour: the anomalous windows go through the VAE a second time, with a new
+    epsilon draw, to form the classifier's residual channel.  reuse_recon=True scores and reconstructs in ONE pass per batch and
+    builds the residual channel from that same reconstruction: one VAE forward per window instead of up
+    to two; the gate decision is identical in distribution, the classifier sees the draw that tripped the gate."""
     vae.eval(); cnn.eval()
     N = Z.size(0)
-    mse = score_windows(vae, Z, batch)
     y_pred = torch.zeros(N, dtype=torch.int64, device=Z.device)
     p_struct = torch.zeros(N, dtype=torch.float32, device=Z.device)
+    if reuse_recon:
+        # scores and reconstructions of every window first (no host synchronisation inside the loop; the reconstructions cost one more
+        # copy of the window set in HBM), then the classifier over the anomalous ones in full batches
+        mse = torch.empty(N, dtype=torch.float32, device=Z.device)
+        recon = torch.empty_like(Z)
+        for i in range(0, N, batch):
+            mse[i:i + batch], recon[i:i + batch] = vae.score_and_reconstruct(Z[i:i + batch])
+        idx = torch.nonzero(mse > threshold, as_tuple=False).flatten()
+        for j in range(0, idx.numel(), batch):
+            sel = idx[j:j + batch]
+            logits = cnn(build_cnn_input(Z.index_select(0, sel), recon.index_select(0, sel)))
+            cls, p1 = predict(logits)
+            y_pred.index_copy_(0, sel, cls + 1)
+            p_struct.index_copy_(0, sel, p1)
+        return mse, y_pred, p_struct
+    mse = score_windows(vae, Z, batch)
     idx = torch.nonzero(mse > threshold, as_tuple=False).flatten()
     for j in range(0, idx.numel(), batch):
         sel = idx[j:j + batch]
@@ -77,12 +97,12 @@ def score_windows_sharded(vae, Z: torch.Tensor, batch: int = 512, group=None) ->
     return _gather_sharded(local, Z.size(0), group)
 
 
-def hybrid_predict_sharded(vae, cnn, Z: torch.Tensor, threshold: float, batch: int = 512, group=None):
+def hybrid_predict_sharded(vae, cnn, Z: torch.Tensor, threshold: float, batch: int = 512, group=None, reuse_recon: bool = False):
     """hybrid_predict over the ranks of `group`; returns (mse, y_pred, p_struct) of all N windows on every rank."""
     _, rank, world = _world(group)
     if world == 1:
-        return hybrid_predict(vae, cnn, Z, threshold, batch)
-    mse, y, p = hybrid_predict(vae, cnn, Z[rank::world].contiguous(), threshold, batch)
+        return hybrid_predict(vae, cnn, Z, threshold, batch, reuse_recon)
+    mse, y, p = hybrid_predict(vae, cnn, Z[rank::world].contiguous(), threshold, batch, reuse_recon)
     n = Z.size(0)
     return _gather_sharded(mse, n, group), _gather_sharded(y, n, group), _gather_sharded(p, n, group)
 

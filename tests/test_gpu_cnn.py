@@ -127,6 +127,37 @@ def test_build_input_and_hybrid_pipeline_match_reference():
     assert maxdiff(p_struct, g["p_struct"]) < TOL
 
 
+def test_hybrid_single_pass_reuses_the_gate_reconstruction():
+    """reuse_recon=True: ONE VAE forward per window.  With the gate's epsilon draw injected, the scores equal the
+    golden's first pass, and every anomalous window is classified on the reconstruction of that same draw — checked against the
+    module-level calls (vae forward with the same draw, residual channel, classifier)."""
+    from Scripts.Models.temporal_vae import TemporalVAE
+    from shm_hip.cnn import build_cnn_input
+    from shm_hip.pipeline import hybrid_predict
+    g = load_golden("pipeline_mini")
+    vae = TemporalVAE(12, 16, 32, 2, 0.3)
+    vae.load_state_dict({k: torch.tensor(v) for k, v in split_prefix(g, "vae.").items()}, strict=True)
+    vae = vae.cuda().eval()
+    cnn = build_cnn(dict(T=100, D=12), split_prefix(g, "cnn.")).eval()
+    Z = torch.tensor(g["Z"]).cuda()
+    thr = float(g["thr"])
+    with inject_eps([torch.tensor(g["eps1"])]):
+        mse, y_pred, p_struct = hybrid_predict(vae, cnn, Z, thr, batch=Z.size(0), reuse_recon=True)
+    assert maxdiff(mse, g["mse"]) < TOL                       # same first draw as the reference's scoring pass
+    with torch.no_grad(), inject_eps([torch.tensor(g["eps1"])]):
+        xhat, _, _ = vae(Z)
+    sel = torch.nonzero(mse > thr).flatten()
+    assert 0 < sel.numel() < Z.size(0)
+    with torch.no_grad():
+        logits = cnn(build_cnn_input(Z[sel], xhat[sel]))
+    want = torch.zeros_like(y_pred); want[sel] = logits.argmax(1) + 1
+    assert torch.equal(y_pred, want)
+    assert maxdiff(p_struct[sel], torch.softmax(logits, 1)[:, 1].cpu().numpy()) < 1e-5 and float(p_struct.sum() - p_struct[sel].sum()) == 0.0
+    # several batches: same labels for the same draws is not expected (one draw per batch), but shapes / gating must hold
+    mse2, y2, p2 = hybrid_predict(vae, cnn, Z, thr, batch=7, reuse_recon=True)
+    assert mse2.shape == mse.shape and bool(((y2 > 0) == (mse2 > thr)).all())
+
+
 def test_cnn_refuses_cpu_and_bad_shapes():
     g = load_golden("cnn_eval_ref")
     m = build_cnn(g["cfg"], split_prefix(g, "p."))
