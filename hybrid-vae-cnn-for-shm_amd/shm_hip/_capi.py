@@ -8,7 +8,10 @@ from __future__ import annotations
 import ctypes as C
 from pathlib import Path
 
-_LIB_PATH = Path(__file__).resolve().parent.parent / "csrc" / "libshm_hip.so"
+import os
+
+# SHM_HIP_LIB: another build of the same library (A/B measurements on one box); the default is the in-tree build
+_LIB_PATH = Path(os.environ.get("SHM_HIP_LIB") or Path(__file__).resolve().parent.parent / "csrc" / "libshm_hip.so")
 
 SHM_PREC_F32, SHM_PREC_BF16 = 0, 1
 
