@@ -110,6 +110,34 @@ def test_train_mode_dropout_matches_oracle_with_same_mask():
             assert maxdiff(grads[k], v) < 2e-4 * np.abs(v).max() + 1e-7, k
 
 
+@pytest.mark.parametrize("B,T,D", [(5, 10, 5), (37, 36, 12), (3, 7, 4), (130, 64, 8), (2, 21, 6)])
+def test_odd_shapes_train_step_matches_oracle(B, T, D):
+    """Window shapes off the two golden ones: odd heights (MaxPool floors), widths that are not powers of two, position counts that
+    are not multiples of 4 / 16 (the matrix-pipe kernels pad or hand over to the vector kernels), batches above one workgroup per CU."""
+    from oracle.cnn_oracle import CNNOracle
+    from Scripts.Models.cnn_model import CNN
+    from shm_hip.trainer import CNNTrainer
+    torch.manual_seed(B * 1000 + T * 10 + D)
+    m = CNN(2, 2, 0.0, seq_len=T, num_features=D).cuda().train()
+    with torch.no_grad():                                   # non-trivial BN affine so that every gradient path carries signal
+        for bn in (m.conv1[1], m.conv2[1]):
+            bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.3, 0.3)
+    p0 = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    rng = np.random.default_rng(B + T + D)
+    x = rng.standard_normal((B, 2, T, D)).astype(np.float32)
+    y = rng.integers(0, 2, B).astype(np.int64)
+    tr = CNNTrainer(m, lr=1e-4, weight_decay=5e-5)
+    loss = float(tr.step(torch.tensor(x).cuda(), torch.tensor(y).cuda())[0])
+    o = CNNOracle(p0)
+    logits = o.forward(x, train=True)
+    ref_loss, ref_g = o.loss_and_grads(logits, y)
+    assert abs(loss - ref_loss) < 1e-5 * max(1.0, abs(ref_loss))
+    grads = dict(zip([k for k, _, _ in tr.engine.layout], tr.engine.split(tr.grads)))
+    for k, v in ref_g.items():
+        if k not in CONV_BIAS:
+            assert maxdiff(grads[k], v) < 2e-4 * np.abs(v).max() + 1e-7, (k, B, T, D)
+
+
 def test_build_input_and_hybrid_pipeline_match_reference():
     """G9: score -> gate -> second VAE pass -> residual channel -> CNN -> labels, both eps draws injected."""
     from Scripts.Models.temporal_vae import TemporalVAE
