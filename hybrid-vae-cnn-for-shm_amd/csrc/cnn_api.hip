@@ -18,7 +18,7 @@ struct shm_cnn_plan {
     int64_t c1w, c1b, g1, b1, c2w, c2b, g2, b2, f1w, f1b, f2w, f2b, n_params;
     // workspace byte offsets
     size_t y1, p1, i1, y2, p2, i2, z1, a1, logits, dlogits, da1, dz1, dflat, dy2, dp1, dy1;
-    size_t part1, part2, mean1, rstd1, scale1, shift1, mean2, rstd2, scale2, shift2, k1, k2, wpart, gemm_partial, colsum_scratch;
+    size_t part1, part2, mean1, rstd1, scale1, shift1, mean2, rstd2, scale2, shift2, k1, k2, wpart, wpart1, gemm_partial, gemm_partial2, colsum_scratch, colsum_scratch2;
     size_t gemm_partial_elems;
     size_t ws_bytes;
     bool fwd_saved, loss_done;
@@ -120,6 +120,10 @@ extern "C" int shm_cnn_plan_create(const shm_cnn_config* cfg, int32_t B, int32_t
         p->gemm_partial_elems = gp;
         p->gemm_partial = take(4 * (gp ? gp : 1));
         p->colsum_scratch = take(4 * colsum_scratch_elems(B, FC1));
+        // second set: every reduction of the backward pass runs in ONE launch at its end, so no partial buffer may be reused before
+        p->wpart1 = take(4 * Bz * (C1 * 2 * 9 + C1));
+        p->gemm_partial2 = take(4 * (gp ? gp : 1));
+        p->colsum_scratch2 = take(4 * colsum_scratch_elems(B, FC1));
     }
     p->ws_bytes = off;
     *out = p;
@@ -185,22 +189,23 @@ extern "C" int shm_cnn_backward(shm_cnn_plan* p, const float* params, const floa
     hipStream_t s = (hipStream_t)stream;
     const int B = p->B, NC = p->cfg.num_classes, F = p->F;
     const float* dl = d_logits ? d_logits : at<float>(ws, p->dlogits);
-    float* cs = at<float>(ws, p->colsum_scratch);
-    auto gemm = [&](const float* A, int M, const float* Bm, int N, float* C) -> int {
+    ReduceJobs rjobs;                                        // every split-K / per-window partial of this pass, reduced in one launch at the end
+    rjobs.n = 0;
+    auto gemm = [&](const float* A, int M, const float* Bm, int N, float* C, size_t part_off) -> int {
         GemmTnArgs g;
         memset(&g, 0, sizeof(g));
         g.A = A; g.lda = M; g.Bm = Bm; g.ldb = N; g.C = C; g.ldc = N; g.R = B; g.M = M; g.N = N;
-        g.partial = at<float>(ws, p->gemm_partial); g.partial_elems = p->gemm_partial_elems;
-        return launch_gemm_tn_f32(g, s);
+        g.partial = at<float>(ws, part_off); g.partial_elems = p->gemm_partial_elems;
+        return launch_gemm_tn_f32(g, s, &rjobs);
     };
     // fc2: dW = dl^T a1, db = colsum(dl), da1 = dl W2 with the dropout and ReLU masks of fc1 re-applied -> dz1
-    if ((rc = gemm(dl, NC, at<float>(ws, p->a1), FC1, grads + p->f2w))) return rc;
-    if ((rc = launch_colsum(dl, NC, B, NC, grads + p->f2b, nullptr, cs, s))) return rc;
+    if ((rc = gemm(dl, NC, at<float>(ws, p->a1), FC1, grads + p->f2w, p->gemm_partial))) return rc;
+    if ((rc = launch_colsum(dl, NC, B, NC, grads + p->f2b, nullptr, at<float>(ws, p->colsum_scratch), s, &rjobs))) return rc;
     if ((rc = cnn_linear_bwd_dx(B, FC1, NC, dl, params + p->f2w, at<float>(ws, p->z1), at<float>(ws, p->dz1), p->drop_p_used, p->drop_seed, s))) return rc;
     // fc1
     const float* dz1 = at<float>(ws, p->dz1);
-    if ((rc = gemm(dz1, FC1, at<float>(ws, p->p2), F, grads + p->f1w))) return rc;
-    if ((rc = launch_colsum(dz1, FC1, B, FC1, grads + p->f1b, nullptr, cs, s))) return rc;
+    if ((rc = gemm(dz1, FC1, at<float>(ws, p->p2), F, grads + p->f1w, p->gemm_partial2))) return rc;
+    if ((rc = launch_colsum(dz1, FC1, B, FC1, grads + p->f1b, nullptr, at<float>(ws, p->colsum_scratch2), s, &rjobs))) return rc;
     if ((rc = cnn_linear_bwd_dx(B, F, FC1, dz1, params + p->f1w, nullptr, at<float>(ws, p->dflat), 0.f, 0, s))) return rc;
     // block 2
     float* wpart = at<float>(ws, p->wpart);
@@ -213,21 +218,22 @@ extern "C" int shm_cnn_backward(shm_cnn_plan* p, const float* params, const floa
         // scratch row (the tail of wpart's last row is free: reuse colsum scratch sized >= that) then scatter
         // straight into the two gradient tensors: the weight block and the bias block of every partial row, each with the row stride
         const size_t nw = (size_t)C2 * C1 * 9, n = nw + C2;
-        if ((rc = launch_reduce_partials_strided(wpart, B, nw, n, grads + p->c2w, s))) return rc;
-        if ((rc = launch_reduce_partials_strided(wpart + nw, B, (size_t)C2, n, grads + p->c2b, s))) return rc;
+        if ((rc = reduce_jobs_add(rjobs, wpart, B, nw, n, grads + p->c2w, nullptr))) return rc;
+        if ((rc = reduce_jobs_add(rjobs, wpart + nw, B, (size_t)C2, n, grads + p->c2b, nullptr))) return rc;
     }
     if ((rc = cnn_conv_bwd_data2(B, p->H1, p->W1, at<float>(ws, p->dy2), params + p->c2w, at<float>(ws, p->dp1), s))) return rc;
     // block 1
     if ((rc = cnn_bn_bwd(B, C1, p->H0, p->W0, at<float>(ws, p->dp1), at<unsigned char>(ws, p->i1), at<float>(ws, p->y1), at<float>(ws, p->mean1),
                          at<float>(ws, p->rstd1), params + p->g1, at<float>(ws, p->part1), at<float>(ws, p->k1), at<float>(ws, p->k2),
                          grads + p->g1, grads + p->b1, at<float>(ws, p->dy1), s))) return rc;
-    if ((rc = cnn_conv_bwd_weight(1, B, p->H0, p->W0, at<float>(ws, p->dy1), x, wpart, s))) return rc;
+    float* wpart1 = at<float>(ws, p->wpart1);
+    if ((rc = cnn_conv_bwd_weight(1, B, p->H0, p->W0, at<float>(ws, p->dy1), x, wpart1, s))) return rc;
     {
         const size_t nw = (size_t)C1 * 2 * 9, n = nw + C1;
-        if ((rc = launch_reduce_partials_strided(wpart, B, nw, n, grads + p->c1w, s))) return rc;
-        if ((rc = launch_reduce_partials_strided(wpart + nw, B, (size_t)C1, n, grads + p->c1b, s))) return rc;
+        if ((rc = reduce_jobs_add(rjobs, wpart1, B, nw, n, grads + p->c1w, nullptr))) return rc;
+        if ((rc = reduce_jobs_add(rjobs, wpart1 + nw, B, (size_t)C1, n, grads + p->c1b, nullptr))) return rc;
     }
-    return SHM_OK;
+    return launch_reduce_batch(rjobs, s);
 }
 
 extern "C" int shm_cnn_build_input(int32_t B, int32_t T, int32_t D, const float* z, const float* zhat, float* xin, void* stream) {

@@ -100,7 +100,7 @@ int launch_reduce_batch(ReduceJobs& jobs, hipStream_t s);
 int launch_gemm_tn_f32(const GemmTnArgs& a, hipStream_t s, ReduceJobs* defer = nullptr);
 size_t gemm_tn_partial_elems(int R, int M, int N);
 // out[n] = sum_r A[r*lda + n], written to out0 and (if non-null) out1; scratch: colsum_scratch_elems(R,N) floats
-int launch_colsum(const float* A, int lda, int R, int N, float* out0, float* out1, float* scratch, hipStream_t s);
+int launch_colsum(const float* A, int lda, int R, int N, float* out0, float* out1, float* scratch, hipStream_t s, ReduceJobs* defer = nullptr);
 size_t colsum_scratch_elems(int R, int N);
 // narrow product out[n][m] = sum_r Bn[r][n] A[r][m] (N <= 16 channels; trans_out writes out[m][n]); A fp32 or bf16
 // bsum_out (optional, natural layout only): [N] column sums of Bn (the bias gradient that goes with the product)

@@ -800,10 +800,11 @@ int launch_reduce_partials_pair(const float* partial, int nparts, size_t n, floa
     return SHM_OK;
 }
 
-int launch_colsum(const float* A, int lda, int R, int N, float* out0, float* out1, float* scratch, hipStream_t s) {
+int launch_colsum(const float* A, int lda, int R, int N, float* out0, float* out1, float* scratch, hipStream_t s, ReduceJobs* defer) {
     const int chunks = ceil_div(R, cs_rows(R));
     SHM_LAUNCH(colsum_kernel, dim3(ceil_div(N, 64), chunks), dim3(256), 0, s, A, lda, R, N, scratch);
     SHM_LAUNCH_CHECK();
+    if (defer) return reduce_jobs_add(*defer, scratch, chunks, (size_t)N, (size_t)N, out0, out1);   // same fixed-order sum, in the batch launch
     return launch_reduce_partials(scratch, chunks, (size_t)N, out0, out1, s);
 }
 int launch_pack_fwd_f32(const float* W, int H, int K, float* dst, hipStream_t s) {
