@@ -129,6 +129,49 @@ def cpu_baseline(sample_windows=128, max_steps=3, budget_s=25.0):
                       f"{cores} threads; same step semantics as the GPU leg"}
 
 
+def cnn_workload(args):
+    """Secondary line: train step of the 4DOF fault classifier (window + squared-residual channels, 2 x 256 x 4) at 512 windows per
+    step, fp32 (every product on the exact-fp32 MFMA), plus the eval forward.  One GPU."""
+    import torch
+    from Scripts.Models.cnn_model import CNN
+    from shm_hip.trainer import CNNTrainer
+    if args.gpus != 1:
+        raise SystemExit("--workload cnn is a single-GPU line")
+    torch.manual_seed(42)
+    m = CNN(2, 2, 0.5, seq_len=T, num_features=D).cuda().train()
+    tr = CNNTrainer(m, lr=1e-4, weight_decay=5e-5)
+    g = torch.Generator().manual_seed(42)
+    x = torch.randn(16 * B_PER_GPU, 2, T, D, generator=g).cuda()
+    y = torch.randint(0, 2, (16 * B_PER_GPU,), generator=g).cuda()
+
+    def run(k0, k):
+        for i in range(k0, k0 + k):
+            b = (i % 16) * B_PER_GPU
+            tr.step(x[b:b + B_PER_GPU], y[b:b + B_PER_GPU])
+    run(0, args.warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.warmup, args.steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    m.eval()
+    with torch.no_grad():
+        for _ in range(3):
+            m(x[:B_PER_GPU])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            m(x[(i % 16) * B_PER_GPU:(i % 16 + 1) * B_PER_GPU])
+        torch.cuda.synchronize()
+        de = time.perf_counter() - t1
+    print(json.dumps({"metric": "windows/sec CNN train (4DOF classifier, 2x256x4 windows, bs512)", "value": round(B_PER_GPU * args.steps / dt, 2),
+                      "unit": "windows/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+                      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                      "config": {"workload": "4DOF CNN train step: conv3x3(2->16)+BN+ReLU+pool, conv3x3(16->32)+BN+ReLU+pool, fc 2048->128 (+dropout 0.5), "
+                                             "fc 128->2, cross-entropy, Adam(1e-4, wd 5e-5); 512 windows of 2 x 256 x 4 per step", "global_batch": B_PER_GPU},
+                      "eval_forward": {"value": round(B_PER_GPU * args.steps / de, 2), "unit": "windows/s", "ms_per_batch": round(1e3 * de / args.steps, 4)}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -140,7 +183,12 @@ def main():
                     help="bf16 (default): bf16 MFMA operands, fp32 accumulate/state/master weights — BASELINE.json configs[1]; "
                          "fp32: exact-f32 MFMA parity path (1e-4 vs the reference)")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the short fp32 parity-path measurement (N=1 only)")
+    ap.add_argument("--workload", choices=["vae", "cnn"], default="vae",
+                    help="vae (default): the headline LSTM-VAE train step (BASELINE.json metric); cnn: the 4DOF classifier's train step "
+                         "(BASELINE.json configs[2], secondary line, N = 1 only)")
     args = ap.parse_args()
+    if args.workload == "cnn":
+        return cnn_workload(args)
 
     import torch
     import torch.distributed as dist
