@@ -119,9 +119,14 @@ __global__ void __launch_bounds__(512) conv3x3_fwd_mfma_kernel(const float* __re
                                                                const float* __restrict__ bias, float* __restrict__ y,
                                                                float* __restrict__ part, int H, int W) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    constexpr int NK = CIN * 9, KS = (NK + 3) / 4, MT = COUT / 16, NWV = 8;
+    // MTW output-channel tiles per wave: all of them while the weights fit comfortably in registers (conv1: 1 x 5 values), ONE when
+    // they would not (conv2: 36 values per tile; two tiles per wave needed 187 VGPRs = one workgroup per CU) — then the waves are
+    // split into MT groups and each group walks the position tiles for its own output-channel tile.
+    constexpr int NK = CIN * 9, KS = (NK + 3) / 4, MT = COUT / 16, NWV = 8, MTW = KS * MT <= 40 ? MT : 1, MG = MT / MTW;
+    static_assert(NWV % MG == 0, "wave groups");
     const int HW = H * W, WP = W + 2, XP = (H + 2) * WP, ntiles = (HW + 15) / 16;
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
+    const int mg = wave % MG, m0 = mg * MTW;                  // this wave's output-channel tiles: m0 .. m0 + MTW - 1
     float* xs = sm;                                           // [CIN][H + 2][W + 2], zero halo
     float* red = sm + ((CIN * XP + 3) & ~3);                  // STATS: [NWV][COUT][2]
     // eight loads in flight per thread: issued one per trip, every global read would wait out its full latency before the next
@@ -137,54 +142,56 @@ __global__ void __launch_bounds__(512) conv3x3_fwd_mfma_kernel(const float* __re
         for (int u = 0; u < 8; ++u)
             if (e0 + u * 512 < CIN * XP) xs[e0 + u * 512] = v[u];
     }
-    // A: lane (q, j) holds W[m * 16 + j][4 s + q]; B offsets: k = 4 s + q -> (ci, tap) -> ci * XP + dh * WP + dw
-    float a[MT][KS];
+    // A: lane (q, j) holds W[(m0 + m) * 16 + j][4 s + q]; B offsets: k = 4 s + q -> (ci, tap) -> ci * XP + dh * WP + dw
+    float a[MTW][KS];
     int koff[KS];
 #pragma unroll
     for (int s2 = 0; s2 < KS; ++s2) {
         const int k = 4 * s2 + q, ok = k < NK, kk = ok ? k : 0, ci = kk / 9, tap = kk - ci * 9;
         koff[s2] = ci * XP + (tap / 3 - 1) * WP + (tap % 3 - 1);
 #pragma unroll
-        for (int m = 0; m < MT; ++m) a[m][s2] = ok ? w[(size_t)(m * 16 + j) * NK + k] : 0.f;      // zero weight: the padded k contributes nothing
+        for (int m = 0; m < MTW; ++m) a[m][s2] = ok ? w[(size_t)((m0 + m) * 16 + j) * NK + k] : 0.f;      // zero weight: the padded k contributes nothing
     }
-    float bia[MT][4], s1[MT][4], s2v[MT][4];
+    float bia[MTW][4], s1[MTW][4], s2v[MTW][4];
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int m = 0; m < MTW; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { bia[m][r] = bias[m * 16 + 4 * q + r]; s1[m][r] = 0.f; s2v[m][r] = 0.f; }
+        for (int r = 0; r < 4; ++r) { bia[m][r] = bias[(m0 + m) * 16 + 4 * q + r]; s1[m][r] = 0.f; s2v[m][r] = 0.f; }
     __syncthreads();
-    for (int nt = wave; nt < ntiles; nt += NWV) {
+    for (int nt = wave / MG; nt < ntiles; nt += NWV / MG) {
         const int p = nt * 16 + j, pc = p < HW ? p : HW - 1, h = pc / W, ww = pc - h * W;
         const float* xb = xs + (h + 1) * WP + (ww + 1);
-        f32x4 acc[MT];
+        f32x4 acc[MTW];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = f32x4{bia[m][0], bia[m][1], bia[m][2], bia[m][3]};
+        for (int m = 0; m < MTW; ++m) acc[m] = f32x4{bia[m][0], bia[m][1], bia[m][2], bia[m][3]};
 #pragma unroll
         for (int s3 = 0; s3 < KS; ++s3) {
             const float bv = xb[koff[s3]];
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m] = mfma_f32_16x16x4(a[m][s3], bv, acc[m]);
+            for (int m = 0; m < MTW; ++m) acc[m] = mfma_f32_16x16x4(a[m][s3], bv, acc[m]);
         }
         if (p < HW) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+            for (int m = 0; m < MTW; ++m)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float v = acc[m][r];
-                    y[((size_t)b * COUT + m * 16 + 4 * q + r) * HW + p] = v;
+                    y[((size_t)b * COUT + (m0 + m) * 16 + 4 * q + r) * HW + p] = v;
                     if (STATS) { s1[m][r] += v; s2v[m][r] = fmaf(v, v, s2v[m][r]); }
                 }
         }
     }
     if (STATS) {
+        // every wave leaves a row [COUT][2] (zeros for the channel tiles it does not own); fixed-order sum over the waves
+        for (int e = lane; e < 2 * COUT; e += 64) red[wave * COUT * 2 + e] = 0.f;
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MTW; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float u = s1[m][r], v = s2v[m][r];
 #pragma unroll
                 for (int off = 1; off < 16; off <<= 1) { u += __shfl_xor(u, off, 64); v += __shfl_xor(v, off, 64); }
-                if (j == 0) { red[(wave * COUT + m * 16 + 4 * q + r) * 2] = u; red[(wave * COUT + m * 16 + 4 * q + r) * 2 + 1] = v; }
+                if (j == 0) { red[(wave * COUT + (m0 + m) * 16 + 4 * q + r) * 2] = u; red[(wave * COUT + (m0 + m) * 16 + 4 * q + r) * 2 + 1] = v; }
             }
         __syncthreads();
         for (int e = tid; e < 2 * COUT; e += 512) {
@@ -825,9 +832,9 @@ int cnn_conv_fwd(int layer, int B, int H, int W, const float* x, const float* w,
     const int HW = H * W;
     int rc;
     // conv1 (2 -> 16 channels, memory-bound) runs on the matrix pipe: 16 vs 29 us at the north-star shape.  conv2 as the same kernel
-    // holds one 8-wave workgroup per CU (187 VGPRs): with at most one workgroup per CU (B <= 256, e.g. the reference's 100-window
-    // batches) it beats the vector kernel below (eval 0.071 vs 0.088 ms), with two rounds (B = 512) it measured 61 us against 41 us,
-    // so larger batches stay on the vector path.  SHM_CNN_VALU_CONV / SHM_CNN_MFMA_CONV2: measurement knobs.
+    // (one output-channel tile per wave, 119 VGPRs, two workgroups per CU) beats the vector kernel below at small batches (eval
+    // 0.071 vs 0.088 ms at the reference's 100-window batches) and only ties it at B = 512 (same-box A/B: train 0.351 vs 0.354 ms,
+    // eval 0.086 vs 0.085), so larger batches stay on the vector path.  SHM_CNN_VALU_CONV / SHM_CNN_MFMA_CONV2: measurement knobs.
     if (!getenv("SHM_CNN_VALU_CONV")) {
         if (layer == 1) return conv_fwd_mfma<2, 16>(B, H, W, x, w, bias, y, part, s);
         if (B <= 256 || getenv("SHM_CNN_MFMA_CONV2")) return conv_fwd_mfma<16, 32>(B, H, W, x, w, bias, y, part, s);
