@@ -226,10 +226,16 @@ def main():
     data = torch.randn(n_resident, T, D, generator=gen).to(dev)
     n_batches = n_resident // B_PER_GPU
 
-    def run(k0, k):
+    marks = []                         # one event per timed step (enqueued, never waited on inside the loop): per-step spread afterwards
+
+    def run(k0, k, mark=False):
         for i in range(k0, k0 + k):
             b = i % n_batches
             trainer.step(data[b * B_PER_GPU:(b + 1) * B_PER_GPU], KL_W)
+            if mark:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                marks.append(ev)
 
     def barrier():
         if world > 1:
@@ -240,10 +246,15 @@ def main():
     run(0, args.warmup)
     torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
     log(f"warm-up done in {time.perf_counter() - tw:.2f}s; timing {args.steps} steps")
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev0.record()
     t0 = time.perf_counter()
-    run(args.warmup, args.steps)
+    run(args.warmup, args.steps, mark=True)
     torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    per_step = sorted(a.elapsed_time(b2) for a, b2 in zip([ev0] + marks[:-1], marks))      # GPU time between consecutive step ends, ms
+    pct = lambda f: round(per_step[min(len(per_step) - 1, int(f * len(per_step)))], 4)
+    step_ms = {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9)} if per_step else None
     log(f"timed region: {dt:.3f}s for {args.steps} steps")
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -292,6 +303,7 @@ def main():
                        "global_batch": world * B_PER_GPU, "seq_len": T, "parallelism": f"dp{world}"},
             "alg_flops_per_window_step": step_flops,
             "whole_step_mfma_frac": round(value * step_flops / (world * PEAK_TFLOPS[dt_key] * 1e12), 5),
+            "step_ms": step_ms,
             "final_stats": {"loss": stats[0], "recon": stats[1], "kl": stats[2], "grad_norm": stats[3]},
             "roofline": roof,
         }
