@@ -67,6 +67,8 @@ def _load():
                                       vp, C.c_int32, vp]),
         "shm_sim_sensor_fault": (C.c_int, [vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double,
                                            vp, vp, C.c_int32, vp]),
+        "shm_peak_mfma": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, vp, C.POINTER(C.c_double), vp]),
+        "shm_peak_hbm": (C.c_int, [vp, vp, C.c_size_t, C.c_int32, vp, C.POINTER(C.c_double), vp]),
         "shm_window_gather": (C.c_int, [vp, C.c_int64, C.c_int32, vp, C.c_int32, C.c_int32, vp, vp, C.c_float, vp, vp]),
         "shm_cnn_eval_loss": (C.c_int, [vp, vp, C.c_int32, C.c_int32, vp, vp]),
         "shm_vae_eval_loss": (C.c_int, [vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, vp, vp]),

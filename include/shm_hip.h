@@ -222,6 +222,14 @@ int shm_sim_newmark(const double* sys, const float* force, int32_t shared_force,
 int shm_sim_sensor_fault(const void* src, void* dst, int32_t is_f32, int32_t R, int32_t steps, int32_t nd, int32_t kind, int32_t dof,
                          double rel_mag, const double* z, const int32_t* idx, int32_t nz, void* stream);
 
+/* ---- measured ceilings of the box (measurement only; SURVEY §8d asks for the measured peak beside the nominal one) ------------------
+ * shm_peak_mfma: every wave of 256 * blocks_per_cu four-wave workgroups issues iters x 8 independent MFMAs (bf16 != 0:
+ * v_mfma_f32_16x16x32_bf16, else v_mfma_f32_16x16x4_f32) with register operands; *tflops = the rate of the second of two passes.
+ * shm_peak_hbm: one pass over `bytes` with 16-byte accesses — mode 0 read, 1 write, 2 copy (read + write counted); *gbps likewise.
+ * scratch: one device float.  Both synchronise the stream. */
+int shm_peak_mfma(int32_t bf16, int32_t blocks_per_cu, int32_t iters, float* scratch, double* tflops, void* stream);
+int shm_peak_hbm(const void* src, void* dst, size_t bytes, int32_t mode, float* scratch, double* gbps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
