@@ -235,7 +235,7 @@ extern "C" int shm_vae_plan_create(const shm_vae_config* cfg, int32_t B, int32_t
                 if (training) {
                     li.WhT = take_bytes(2 * bwd_pack_elems_bf16(H, H));
                     if (l > 0) li.WxT = take_bytes(2 * bwd_pack_elems_bf16(H, li.In));
-                    li.saved = take_bytes(16 * qt * T * 4 * H);         // one 16-byte record per lane (4H lanes) and step
+                    li.saved = take_bytes(12 * qt * T * 4 * H);         // one 12-byte record per lane (4H lanes) and step
                 }
             } else {
                 li.Wx = take(fwd_pack_elems(H, li.In));

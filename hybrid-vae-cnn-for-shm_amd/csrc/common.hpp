@@ -44,6 +44,14 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// BPTT record of the bf16 path: {i,f | g,o | c_{t-1}, tanh(c_t)}, six bf16 = 12 bytes per lane and step.  A struct, not
+// ext_vector_type(3): that type is padded to 16 bytes in memory, which is exactly the quarter this layout saves.
+struct __attribute__((aligned(4))) u32x3 {
+    unsigned v[3];
+    __device__ __forceinline__ unsigned& operator[](int i) { return v[i]; }
+    __device__ __forceinline__ const unsigned& operator[](int i) const { return v[i]; }
+};
+static_assert(sizeof(u32x3) == 12, "12-byte BPTT record");
 
 // D[16x16] += A[16x4] * B[4x16], exact f32 (v_mfma_f32_16x16x4_f32).
 // lane l supplies A[row = l&15][k = l>>4] and B[k = l>>4][col = l&15]; holds D[row = 4*(l>>4)+r][col = l&15], r = 0..3.

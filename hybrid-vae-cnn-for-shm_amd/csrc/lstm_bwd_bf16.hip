@@ -52,7 +52,7 @@ __device__ __forceinline__ float redeal1(const f32x4 a) {
 }
 
 struct Prefetch {            // operands of one time step of this lane's cell, fetched PD = 3 steps ahead
-    u32x4 rec;               // {i,f | g,o (bf16x2 each), c_{t-1}, tanh(c_t)} written by the forward
+    u32x3 rec;               // {i,f | g,o | c_{t-1}, tanh(c_t)} (bf16x2 each) written by the forward
     f32x4 up;                // DH == 1: up[0] = dx of this cell;  DH == 2: dy[b,t,0..3] (raw, multiplied by W_out at use)
 };
 
@@ -97,7 +97,7 @@ __device__ __forceinline__ void lstm_bwd_body(const LstmBwdArgsB& a, const int t
         for (int s = 0; s < KS; ++s) whT[s] = p[s * 64];
     }
 
-    const u32x4* sv = reinterpret_cast<const u32x4*>(a.sv_g) + ((size_t)tile * T * NW + ht) * 64 + lane;
+    const u32x3* sv = reinterpret_cast<const u32x3*>(a.sv_g) + ((size_t)tile * T * NW + ht) * 64 + lane;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     auto fetch = [&](Prefetch& P, int t) {
@@ -124,7 +124,7 @@ __device__ __forceinline__ void lstm_bwd_body(const LstmBwdArgsB& a, const int t
     auto step = [&](Prefetch& P, int t) {
         // Pin the consumption point of this slot: without it the compiler hoists the unpacking of the LATER slots into this
         // step, i.e. touches registers whose loads are still in flight and turns the counted waits into a drain.
-        asm volatile("" : "+v"(P.rec), "+v"(P.up));
+        asm volatile("" : "+v"(P.rec.v[0]), "+v"(P.rec.v[1]), "+v"(P.rec.v[2]), "+v"(P.up));
         bf16_t* dpl = dp_lds + (t & 1) * PBUF;
         float dha;
         if constexpr (DH == 2) {
@@ -136,7 +136,7 @@ __device__ __forceinline__ void lstm_bwd_body(const LstmBwdArgsB& a, const int t
         // into one by the compiler: both pairs came out as (i, f))
         const float s_i = __uint_as_float(P.rec[0] << 16), s_f = __uint_as_float(P.rec[0] & 0xffff0000u);
         const float s_g = __uint_as_float(P.rec[1] << 16), s_o = __uint_as_float(P.rec[1] & 0xffff0000u);
-        const float c_prev = __uint_as_float(P.rec[2]), tc = __uint_as_float(P.rec[3]);
+        const float c_prev = __uint_as_float(P.rec[2] << 16), tc = __uint_as_float(P.rec[2] & 0xffff0000u);
         float dpre[4];
         {
             const float dh = dha * vmask + dh_rec;
@@ -251,9 +251,9 @@ __device__ __forceinline__ void lstm_bwd_fused_dx_body(const LstmBwdArgsB& a, co
     const uint32_t thr = drop_threshold(up.drop_p);
     const float dscale = DROP ? 1.0f / (1.0f - up.drop_p) : 1.0f;
 
-    const u32x4* sv = reinterpret_cast<const u32x4*>(a.sv_g) + ((size_t)tile * T * NW + ht) * 64 + lane;
+    const u32x3* sv = reinterpret_cast<const u32x3*>(a.sv_g) + ((size_t)tile * T * NW + ht) * 64 + lane;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    auto fetch = [&](u32x4& R, int t) { R = sv[(size_t)(t < 0 ? 0 : t) * NW * 64]; };
+    auto fetch = [&](u32x3& R, int t) { R = sv[(size_t)(t < 0 ? 0 : t) * NW * 64]; };
 
     // ---- the upper layer's dpre rows: sc1 loads behind the producer's progress word
     const __amdgpu_buffer_rsrc_t up_rsrc = make_rsrc(up.dpre_seq + (size_t)tile * T * WPT * 4 * H, (uint32_t)T * WPT * 4 * H * 2);
@@ -313,15 +313,15 @@ __device__ __forceinline__ void lstm_bwd_fused_dx_body(const LstmBwdArgsB& a, co
     float dc = 0.f, dh_rec = 0.f;
     float tsum[4] = {0.f, 0.f, 0.f, 0.f};
 
-    auto step = [&](u32x4& R, int t, auto subc) {
+    auto step = [&](u32x3& R, int t, auto subc) {
         constexpr int SUB = decltype(subc)::value;         // t & 3 in the main loop, -1 in the peeled steps
-        asm volatile("" : "+v"(R));
+        asm volatile("" : "+v"(R.v[0]), "+v"(R.v[1]), "+v"(R.v[2]));
         bf16_t* dpl = dp_lds + (t & 1) * PBUF;
         const int c = t >> 2;
         const float dha = dxbuf[(((c & 1) * 16) + (t & 3) * 4 + cj) * H + cu];
         const float s_i = __uint_as_float(R[0] << 16), s_f = __uint_as_float(R[0] & 0xffff0000u);
         const float s_g = __uint_as_float(R[1] << 16), s_o = __uint_as_float(R[1] & 0xffff0000u);
-        const float c_prev = __uint_as_float(R[2]), tc = __uint_as_float(R[3]);
+        const float c_prev = __uint_as_float(R[2] << 16), tc = __uint_as_float(R[2] & 0xffff0000u);
         float dpre[4];
         {
             const float dh = dha * vmask + dh_rec;
@@ -371,7 +371,7 @@ __device__ __forceinline__ void lstm_bwd_fused_dx_body(const LstmBwdArgsB& a, co
     if (T & 3) { c1 = ctop - 1; if (c1 >= 0) sync_chunk(c1); }      // the peeled steps use the partial top chunk
     chunk_load(c1 - 1);
 
-    u32x4 R0, R1, R2, R3;
+    u32x3 R0, R1, R2, R3;
     int t = T - 1;
     for (int k = T & 3; k > 0; --k, --t) { fetch(R0, t); step(R0, t, IntC<-1>{}); }
     fetch(R0, t); fetch(R1, t - 1); fetch(R2, t - 2); fetch(R3, t - 3);

@@ -11,7 +11,7 @@
 //   * the accumulator (lane (q,j) = units 4q..4q+3 of window j, only j < 4 meaningful) is re-dealt with DPP row shifts so
 //     that EVERY lane owns exactly one cell: lane (q,jj) = unit 4q + (jj>>2) of window jj&3.  The cell update (10
 //     transcendental instructions) then costs a quarter of the VALU issue of the 16-window mapping, and c_t is one register;
-//   * saved state for BPTT is ONE 16-byte record per lane per step {i,f | g,o (bf16), c_{t-1}, tanh(c_t) (fp32)} in
+//   * saved state for BPTT is ONE 12-byte record per lane per step {i,f | g,o | c_{t-1}, tanh(c_t)} (six bf16) in
 //     fragment order (1 KiB contiguous per wave), stored at the start of the NEXT step, behind the MFMA issue;
 //   * h_t returns to the LDS operand image as bf16; h_seq is tile-blocked row-major (row r' = (tile*T + t)*4 + j) and is
 //     copied out of the completed image one step later as 16-byte coalesced stores;
@@ -234,7 +234,7 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int t
     }
 
     float c = 0.f, h = 0.f;
-    u32x4* sv = SAVE ? reinterpret_cast<u32x4*>(a.sv_g) + ((size_t)tile * T * NW + ht) * 64 + lane : nullptr;
+    u32x3* sv = SAVE ? reinterpret_cast<u32x3*>(a.sv_g) + ((size_t)tile * T * NW + ht) * 64 + lane : nullptr;
 
     // vector-memory instructions wave 0 issues per step besides the flag store (h_seq, record, x prefetch, masked x)
     constexpr int OPS = 1 + (SAVE ? 1 : 0) + (CONSTIN ? 0 : 1) + (DROP ? 1 : 0);
@@ -253,7 +253,7 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int t
             }
         }
     };
-    u32x4 rec_prev = {0u, 0u, 0u, 0u};
+    u32x3 rec_prev = {{0u, 0u, 0u}};
     // X: slot holding x_{t+2}; committed at the end of the step (into the buffer of x_t, whose projection step t-1 consumed)
     // and refilled with x_{t+5}
     auto step = [&](XSlot& X, int t) {
@@ -339,8 +339,8 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int t
             f32x2 a0 = {gi, gf}, a1 = {gg, go};
             rec_prev[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(a0, bf16x2));
             rec_prev[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(a1, bf16x2));
-            rec_prev[2] = __float_as_uint(c_prev);
-            rec_prev[3] = __float_as_uint(tc);
+            f32x2 a2 = {c_prev, tc};
+            rec_prev[2] = __builtin_bit_cast(unsigned, __builtin_convertvector(a2, bf16x2));
         }
         __syncthreads();
     };
