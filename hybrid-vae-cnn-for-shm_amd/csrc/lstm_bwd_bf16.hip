@@ -15,7 +15,7 @@
 //                     dpre_t leaves through the LDS operand image as 16-byte stores (a second ablation showed the
 //                     previous per-lane 8-byte stores into 16 different rows cost 45 % of the kernel);
 //   dx_seq          : MFMA fragment order [r'/16][wave][lane][4] — written by dx_gemm;
-//   saved records   : one 16-byte record per cell and step, fragment order (written by the forward).
+//   saved records   : one 12-byte record per cell and step (six bf16), fragment order (written by the forward).
 // Quad tiles / one cell per lane: see lstm_fwd_bf16.hip.  After the third ablation (per-CU HBM load bandwidth, ~25 GB/s, was
 // the limiter with 16-window tiles on 32 CUs) a workgroup owns 4 windows: 128 CUs, 20 B of loads per lane and step.
 //
