@@ -1,0 +1,39 @@
+"""bench.py prints ONE JSON line with the fields the driver reads (metric / value / unit / n_gpus / steps / warmup / ms_per_step /
+higher_is_better / scaling / vs_baseline / dtype / data / config.workload) plus the roofline and cpu_baseline objects."""
+import json
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(*extra):
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "4", "--warmup", "2", *extra], cwd=str(ROOT), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    return json.loads(lines[0])
+
+
+def test_default_line_has_the_contract_fields():
+    d = _run()
+    assert d["metric"].startswith("windows/sec LSTM-VAE train") and d["unit"] == "windows/s" and d["value"] > 1e4
+    assert (d["n_gpus"], d["steps"], d["warmup"]) == (1, 4, 2) and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["dtype"] == "bf16" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert abs(d["value"] - 512 * 4 / (d["ms_per_step"] * 4e-3)) < 1e-2 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] in ("mfma", "hbm") and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and 0.01 < rf["frac"] < 1.0
+    assert rf["traffic"] is None or rf["traffic"] > 1e8                      # bytes per launch from the committed PMC summary
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["unit"] == "windows/s" and cb["value"] > 1 and cb["cores"] >= 1 and cb["sample"]
+    assert d["fp32_parity_path"]["dtype"] == "f32" and d["step_ms"]["p10"] <= d["step_ms"]["median"] <= d["step_ms"]["p90"]
+
+
+def test_cnn_line():
+    d = _run("--workload", "cnn")
+    assert d["metric"].startswith("windows/sec CNN train") and d["value"] > 1e4 and d["eval_forward"]["value"] > d["value"]
