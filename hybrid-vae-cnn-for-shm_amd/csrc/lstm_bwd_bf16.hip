@@ -154,7 +154,7 @@ __device__ __forceinline__ void lstm_bwd_body(const LstmBwdArgsB& a, const int t
             dpl[(g * 16 + cj) * RS + cu] = (bf16_t)dpre[g];
             tsum[g] += dpre[g];
         }
-        fetch(P, t - 3);                                   // refill the slot: 3 steps of latency cover
+        fetch(P, t - 4);                                   // refill the slot: 4 steps of latency cover
         __syncthreads();
         // every storing wave has, in step t+1, waited until its dpre store of step t+DLY had retired
         if constexpr (PRODUCE) {
@@ -189,18 +189,19 @@ __device__ __forceinline__ void lstm_bwd_body(const LstmBwdArgsB& a, const int t
     };
 
     __syncthreads();                                       // images zeroed, wo_lds visible
-    Prefetch P0, P1, P2;
+    Prefetch P0, P1, P2, P3;
     if (a.dh_last) dh_rec = vmask * a.dh_last[(size_t)bc * H + cu];    // gradient on h_{T-1}
     int t = T - 1;
-    for (int k = T % 3; k > 0; --k, --t) { fetch(P0, t); step(P0, t); }     // peel so that the main loop runs whole triples
-    fetch(P0, t); fetch(P1, t - 1); fetch(P2, t - 2);
+    for (int k = T & 3; k > 0; --k, --t) { fetch(P0, t); step(P0, t); }     // peel so that the main loop runs whole quadruples
+    fetch(P0, t); fetch(P1, t - 1); fetch(P2, t - 2); fetch(P3, t - 3);
     // Drain once here: the waits inside the loop are static, so anything still in flight from the prologue (weights,
     // peeled steps, these first fetches) would otherwise force a vmcnt(0) into every iteration.
     __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0) only
-    for (; t >= 2; t -= 3) {
+    for (; t >= 3; t -= 4) {
         step(P0, t);
         step(P1, t - 1);
         step(P2, t - 2);
+        step(P3, t - 3);
     }
     if constexpr (PRODUCE) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
