@@ -526,7 +526,7 @@ __global__ void __launch_bounds__(256) window_gather_kernel(const float* __restr
 // ------------------------------------------------------------------------------------------------ narrow TN product
 // out[n][m] = sum_r Bn[r][n] * A[r][m]  with n < N <= 16 (channel count): dW_out = d_recon^T h_top, dW_ih(enc0) = dpre^T x.
 // A is streamed once (HBM-bound, 2 columns per thread); Bn is a broadcast load.  Block partials -> reduce_partials.
-constexpr int NARROW_BLOCKS = 512;
+constexpr int NARROW_BLOCKS = 1024;
 template <typename T, int CPT> struct VecLoad;
 template <> struct VecLoad<float, 2> { static __device__ __forceinline__ void ld(const float* p, float (&v)[2]) { const f32x2 t = *reinterpret_cast<const f32x2*>(p); v[0] = t[0]; v[1] = t[1]; } };
 template <> struct VecLoad<float, 8> { static __device__ __forceinline__ void ld(const float* p, float (&v)[8]) {
