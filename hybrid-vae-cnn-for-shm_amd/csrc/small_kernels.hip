@@ -449,18 +449,22 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __res
     if (blockIdx.y == 1) { partial += n_out; out0 = outB; out1 = nullptr; }     // second product of a shared-A GEMM
     const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const size_t i = (size_t)blockIdx.x * 32 + o;          // n = element stride between partials, n_out = outputs
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
     if (i < n_out) {
         int p = grp;
-        for (; p + 24 < nparts; p += 32) {
+        for (; p + 56 < nparts; p += 64) {
             s0 += partial[(size_t)p * n + i];
             s1 += partial[(size_t)(p + 8) * n + i];
             s2 += partial[(size_t)(p + 16) * n + i];
             s3 += partial[(size_t)(p + 24) * n + i];
+            s4 += partial[(size_t)(p + 32) * n + i];
+            s5 += partial[(size_t)(p + 40) * n + i];
+            s6 += partial[(size_t)(p + 48) * n + i];
+            s7 += partial[(size_t)(p + 56) * n + i];
         }
         for (; p < nparts; p += 8) s0 += partial[(size_t)p * n + i];
     }
-    red[grp][o] = (s0 + s1) + (s2 + s3);
+    red[grp][o] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
     __syncthreads();
     if (grp == 0 && i < n_out) {
         const float v = ((red[0][o] + red[1][o]) + (red[2][o] + red[3][o])) + ((red[4][o] + red[5][o]) + (red[6][o] + red[7][o]));
@@ -479,18 +483,22 @@ __global__ void __launch_bounds__(256) reduce_batch_kernel(ReduceJobs jobs) {
     const size_t i = (size_t)(blockIdx.x - jobs.first_block[j]) * 32 + o;
     const float* __restrict__ partial = jb.partial;
     const size_t n = jb.stride;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
     if (i < jb.n_out) {
         int p = grp;
-        for (; p + 24 < jb.nparts; p += 32) {
+        for (; p + 56 < jb.nparts; p += 64) {
             s0 += partial[(size_t)p * n + i];
             s1 += partial[(size_t)(p + 8) * n + i];
             s2 += partial[(size_t)(p + 16) * n + i];
             s3 += partial[(size_t)(p + 24) * n + i];
+            s4 += partial[(size_t)(p + 32) * n + i];
+            s5 += partial[(size_t)(p + 40) * n + i];
+            s6 += partial[(size_t)(p + 48) * n + i];
+            s7 += partial[(size_t)(p + 56) * n + i];
         }
         for (; p < jb.nparts; p += 8) s0 += partial[(size_t)p * n + i];
     }
-    red[grp][o] = (s0 + s1) + (s2 + s3);
+    red[grp][o] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
     __syncthreads();
     if (grp == 0 && i < jb.n_out) {
         const float v = ((red[0][o] + red[1][o]) + (red[2][o] + red[3][o])) + ((red[4][o] + red[5][o]) + (red[6][o] + red[7][o]));
