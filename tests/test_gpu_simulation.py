@@ -220,4 +220,4 @@ def test_s2_windows_and_both_precisions_train_alike():
         a, b = np.array(hist["fp32"][key]), np.array(hist["bf16"][key])
         assert np.isfinite(a).all() and np.isfinite(b).all()
         np.testing.assert_allclose(b, a, rtol=3e-2)
-    # (four epochs on 1.3 k windows do not move the error yet; tools/s2_convergence.py is the long run: profiles/r01_s2_convergence.json)
+    # (four epochs on 1.3 k windows do not move the error yet; tools/s2_convergence.py is the long run: profiles/r01_s2_convergence_seed*.json)
