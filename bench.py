@@ -25,7 +25,7 @@ for p in (str(ROOT), str(ROOT / "hybrid-vae-cnn-for-shm_amd")):
 
 B_PER_GPU, T, D, H, Z, L = 512, 256, 4, 128, 16, 2
 KL_W = 0.5
-PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}       # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "bf16x2": 2500.0}       # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 
 
 def alg_flops_forward_per_window():
@@ -35,20 +35,25 @@ def alg_flops_forward_per_window():
     return F - 2 * G * H * (T - 1)
 
 
-def kernel_alg_flops(name, B, bf16=False):
+def kernel_alg_flops(name, B, path="fp32"):
     """Algorithmic FLOPs of ONE launch of a profiled kernel (MFMA contractions only; pointwise excluded).
-    In the bf16 path dx = dpre.W_ih is a separate time-parallel GEMM (dx_gemm.*); in the fp32 path it is inside lstm_bwd."""
+    path "bf16" / "split": dx = dpre.W_ih is a separate time-parallel GEMM (dx_gemm.*); "fp32": it is inside lstm_bwd.
+    path "split": the input projections of layers 1 (and of decoder layer 0) are their own launches (xproj.*)."""
     G = 4 * H
     kind, _, inst = name.partition(".")
     if kind == "lstm_fwd":
         if inst in ("enc", "dec"):                                          # layer-pipelined launch: both layers of the stack
-            return kernel_alg_flops(f"lstm_fwd.{inst}0", B, bf16) + kernel_alg_flops(f"lstm_fwd.{inst}1", B, bf16)
+            return kernel_alg_flops(f"lstm_fwd.{inst}0", B, path) + kernel_alg_flops(f"lstm_fwd.{inst}1", B, path)
         k_in = {"enc0": D, "enc1": H, "dec0": 0, "dec1": H}[inst]          # dec0: constant input, projected once
+        if path == "split":
+            return B * T * 2 * G * ((D if inst == "enc0" else 0) + H)
         return B * T * 2 * G * (k_in + H) + (B * 2 * G * H if inst == "dec0" else 0)
+    if kind == "xproj":
+        return B * 2 * G * H if inst == "dec0" else B * T * 2 * G * H
     if kind == "lstm_bwd":
         if inst in ("enc", "dec"):                                          # layer-pipelined launch incl. the dx product
             return 2 * B * T * 2 * G * H + B * T * 2 * G * H
-        k_dx = 0 if bf16 else {"enc0": 0, "enc1": H, "dec0": 0, "dec1": H}[inst]   # dx only for layers with a layer below
+        k_dx = 0 if path != "fp32" else {"enc0": 0, "enc1": H, "dec0": 0, "dec1": H}[inst]   # dx only for layers with a layer below
         return B * T * 2 * G * (H + k_dx)
     if kind == "dx_gemm":
         return B * T * 2 * G * H
@@ -179,7 +184,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=2)
-    ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16",
+    ap.add_argument("--precision", choices=["bf16", "fp32", "split"], default="bf16",
                     help="bf16 (default): bf16 MFMA operands, fp32 accumulate/state/master weights — BASELINE.json configs[1]; "
                          "fp32: exact-f32 MFMA parity path (1e-4 vs the reference)")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the short fp32 parity-path measurement (N=1 only)")
@@ -217,7 +222,7 @@ def main():
 
     torch.manual_seed(42)
     model = TemporalVAE(D, Z, H, L, 0.3, precision=args.precision).to(dev).train()
-    dt_key = "bf16" if args.precision == "bf16" else "f32"
+    dt_key = {"bf16": "bf16", "fp32": "f32", "split": "bf16x2"}[args.precision]
     trainer = VAETrainer(model, lr=1e-3, weight_decay=1e-5, max_norm=2.0, seed=42)
 
     # S1 synthetic windows, resident on the device: no H2D inside the timed region
@@ -277,9 +282,8 @@ def main():
         prof = json.loads(buf.value.decode())
         log("kernel profile: " + json.dumps(prof))
         per = {k: v["ms"] / v["calls"] for k, v in prof.items()}
-        is_bf = args.precision == "bf16"
-        dom = max((k for k in per if kernel_alg_flops(k, B_PER_GPU, is_bf) > 0), key=lambda k: per[k])
-        fl = kernel_alg_flops(dom, B_PER_GPU, is_bf)
+        dom = max((k for k in per if kernel_alg_flops(k, B_PER_GPU, args.precision) > 0), key=lambda k: per[k])
+        fl = kernel_alg_flops(dom, B_PER_GPU, args.precision)
         achieved = fl / (per[dom] * 1e-3) / 1e12
         peak = PEAK_TFLOPS[dt_key]
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",

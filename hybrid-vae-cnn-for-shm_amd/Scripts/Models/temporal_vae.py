@@ -5,6 +5,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
+from shm_hip._capi import PRECISIONS
 from shm_hip.vae import VAEEngine, VAEFunction
 
 
@@ -18,8 +19,9 @@ class TemporalVAE(nn.Module):
     default initialisation consumes the torch RNG exactly like the reference and reference checkpoints load
     with strict=True) but are never called — forward() hands the flat parameter buffer to libshm_hip.so.
     Extra keyword-only arguments: layer_norm (False gives the 1_DOF model, 1_DOF/Scripts/Models/temporal_vae.py:7-64);
-    precision: "fp32" (exact-f32 MFMA, the 1e-4 parity path) or "bf16" (bf16 MFMA operands, fp32 accumulate / cell
-    state / master weights — the throughput path, tolerances in DESIGN.md §5).
+    precision: "fp32" (exact-f32 MFMA: bit-level fp32 arithmetic, slow), "split" (every MFMA operand a bf16 pair
+    hi + lo, fp32 accumulate / state: holds the reference's fp32 results to ~1e-6 — the fast 1e-4 parity path) or
+    "bf16" (single bf16 operands, fp32 accumulate / cell state / master weights — the throughput path, tolerances in DESIGN.md §2).
     """
 
     def __init__(
@@ -54,11 +56,11 @@ class TemporalVAE(nn.Module):
                                     batch_first=True, dropout=dropout if num_layers > 1 else 0.0)
         self.output_layer = nn.Linear(hidden_dim, input_dim)
 
-        if precision not in ("fp32", "bf16"):
-            raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(PRECISIONS)}, got {precision!r}")
         self.precision = precision
         self._engine = VAEEngine(input_dim, latent_dim, hidden_dim, num_layers, layer_norm, self.dropout,
-                                 precision=1 if precision == "bf16" else 0)
+                                 precision=PRECISIONS[precision])
         self._drop_gen_calls = 0
 
     # ------------------------------------------------------------------ reference API

@@ -48,6 +48,8 @@ struct LayerInst {
     size_t Wx = 0, Wh = 0, bsum = 0, WhT = 0, WxT = 0;   // byte offsets into the workspace (packed operands)
     size_t h_seq = 0, saved = 0, saved_c = 0;            // bf16 path: saved = BPTT records
     size_t xdrop = 0;                                    // bf16 path, layers >= 1: dropout-masked input sequence
+    // split-precision path: the LO planes / LO fragment arrays that pair with the fields above, and the hoisted input projection
+    size_t Wx_lo = 0, Wh_lo = 0, WhT_lo = 0, WxT_lo = 0, h_lo = 0, xdrop_lo = 0, xproj = 0;
 };
 
 }  // namespace shm
@@ -70,6 +72,7 @@ struct shm_vae_plan {
     size_t h0_bf;           // bf16 path: bf16 copy of the decoder input h0 [qt*WPT, H], written by decoder layer 0's forward
     size_t x_tb;            // bf16 path: tile-blocked bf16 copy of x [Rq, 16], written by encoder layer 0's forward, read by its dW_ih product
     size_t misc;            // bf16 path: [64 B sticky error word of the pair launches][256 zero bytes], zeroed by pack_weights
+    size_t dpre_lo, x_tb_lo, h0_lo;   // split-precision path: LO planes of dpre_seq / x_tb / h0_bf
     size_t params_copy;     // flat fp32 copy of the parameters (head / output layer read them unpacked)
     size_t ws_bytes;
     // call-order state
@@ -88,7 +91,8 @@ static bool config_ok(const shm_vae_config* c) {
     if (c->num_layers < 1 || c->num_layers > 2) { set_error("num_layers %d unsupported (1, 2)", c->num_layers); return false; }
     if (c->latent_dim < 1 || c->latent_dim > 32) { set_error("latent_dim %d unsupported (1..32)", c->latent_dim); return false; }
     if (c->input_dim < 1 || c->input_dim > 16) { set_error("input_dim %d unsupported (1..16)", c->input_dim); return false; }
-    if (c->precision != SHM_PREC_F32 && c->precision != SHM_PREC_BF16) { set_error("precision %d unknown (0 = fp32, 1 = bf16)", c->precision); return false; }
+    if (c->precision != SHM_PREC_F32 && c->precision != SHM_PREC_BF16 && c->precision != SHM_PREC_SPLIT) {
+        set_error("precision %d unknown (0 = fp32, 1 = bf16, 2 = split bf16x2)", c->precision); return false; }
     if (!(c->dropout >= 0.f && c->dropout < 1.f)) { set_error("dropout %f out of range", c->dropout); return false; }
     return true;
 }
@@ -218,7 +222,8 @@ extern "C" int shm_vae_plan_create(const shm_vae_config* cfg, int32_t B, int32_t
     size_t off = 0;
     auto take_bytes = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     auto take = [&](size_t elems) { return take_bytes(elems * sizeof(float)); };
-    const bool bf = cfg->precision == SHM_PREC_BF16;
+    const bool sp = cfg->precision == SHM_PREC_SPLIT;             // split path: the bf16 path's tile-blocked layouts, every operand as hi + lo planes
+    const bool bf = cfg->precision == SHM_PREC_BF16 || sp;
     const size_t tiles = (size_t)ceil_div(B, 16);                 // fp32 path: 16-window tiles
     const size_t qt = (size_t)ceil_div(B, SHM_WPT);               // bf16 path: SHM_WPT-window tiles
     const size_t Rq = (qt * SHM_WPT * T + 15) / 16 * 16;          // bf16 path: tile-blocked rows, padded to whole MFMA fragments
@@ -227,7 +232,20 @@ extern "C" int shm_vae_plan_create(const shm_vae_config* cfg, int32_t B, int32_t
         for (int s = 0; s < 2; ++s) {
             LayerInst& li = s == 0 ? p->enc[l] : p->dec[l];
             li.bsum = take(4 * H);
-            if (bf) {
+            if (sp) {
+                li.Wx = take_bytes(2 * fwd_pack_elems_bf16(H, li.In)); li.Wx_lo = take_bytes(2 * fwd_pack_elems_bf16(H, li.In));
+                li.Wh = take_bytes(2 * fwd_pack_elems_bf16(H, H)); li.Wh_lo = take_bytes(2 * fwd_pack_elems_bf16(H, H));
+                li.h_seq = take_bytes(2 * Rq * H); li.h_lo = take_bytes(2 * Rq * H);
+                if (l > 0) li.xproj = take(Rq * 4 * H);                   // W_ih x_t + b of every step, cell order (whole tiles)
+                else if (li.in_const) li.xproj = take(qt * SHM_WPT * 4 * H);   // once per window
+                if (l > 0 && cfg->dropout > 0.f) { li.xdrop = take_bytes(2 * Rq * H); li.xdrop_lo = take_bytes(2 * Rq * H); }
+                if (training) {
+                    li.WhT = take_bytes(2 * bwd_pack_elems_bf16(H, H)); li.WhT_lo = take_bytes(2 * bwd_pack_elems_bf16(H, H));
+                    if (l > 0) { li.WxT = take_bytes(2 * bwd_pack_elems_bf16(H, li.In)); li.WxT_lo = take_bytes(2 * bwd_pack_elems_bf16(H, li.In)); }
+                    li.saved = take_bytes(16 * qt * T * 4 * H);         // {i,f,g,o} fp32 per cell and step
+                    li.saved_c = take_bytes(8 * qt * T * 4 * H);        // {c_{t-1}, tanh c_t}
+                }
+            } else if (bf) {
                 li.Wx = take_bytes(2 * fwd_pack_elems_bf16(H, li.In));
                 li.Wh = take_bytes(2 * fwd_pack_elems_bf16(H, H));
                 li.h_seq = take_bytes(2 * Rq * H);                        // whole tiles: unconditional stores in the kernel
@@ -249,11 +267,12 @@ extern "C" int shm_vae_plan_create(const shm_vae_config* cfg, int32_t B, int32_t
             }
         }
     }
-    if (bf && L == 2) p->pair_sync = take_bytes(2 * lstm_fwd_pair_sync_bytes(B));      // two blocks, used alternately
+    if (bf && !sp && L == 2) p->pair_sync = take_bytes(2 * lstm_fwd_pair_sync_bytes(B));      // two blocks, used alternately
     if (bf) p->misc = take_bytes(misc_bytes(B));                     // sticky error word | 256 B of zeros | out_fwd's per-tile arrival counters
     if (bf) p->score_part = take((size_t)4 * ceil_div(B, SHM_WPT) * SHM_WPT);
     if (bf) p->x_tb = take_bytes(2 * Rq * 16);
     if (bf) p->h0_bf = take_bytes(2 * qt * SHM_WPT * H);
+    if (sp) { p->x_tb_lo = take_bytes(2 * Rq * 16); p->h0_lo = take_bytes(2 * qt * SHM_WPT * H); }
     p->params_copy = take((size_t)p->n_params);
     p->h_last = take((size_t)B * H); p->eps = take((size_t)B * Z);
     p->y = take((size_t)B * H); p->xhat = take((size_t)B * H); p->rstd = take(B);
@@ -264,8 +283,9 @@ extern "C" int shm_vae_plan_create(const shm_vae_config* cfg, int32_t B, int32_t
         p->dyx = take((size_t)B * H); p->dy = take((size_t)B * H); p->dh_last = take((size_t)B * H); p->dh0 = take((size_t)B * H);
         p->recon = take(BT * D); p->d_recon = take(BT * D); p->d_mu = take((size_t)B * Z); p->d_lv = take((size_t)B * Z);
         p->dpre_seq = bf ? take_bytes(2 * Rq * 4 * H) : take(BT * 4 * H);   // bf16: whole tiles (unconditional stores)
+        if (sp) p->dpre_lo = take_bytes(2 * Rq * 4 * H);
         p->dx_seq = take(bf ? Rq * H : BT * H); p->dpre_tsum = take((size_t)B * 4 * H);
-        if (bf && L == 2) { p->dpre_seq2 = take_bytes(2 * Rq * 4 * H); p->dpre_tsum2 = take((size_t)B * 4 * H); }
+        if (bf && !sp && L == 2) { p->dpre_seq2 = take_bytes(2 * Rq * 4 * H); p->dpre_tsum2 = take((size_t)B * 4 * H); }
         size_t gp = 0;
         auto upd = [&](int R, int M, int N) { const size_t e = gemm_tn_partial_elems(R, M, N); if (e > gp) gp = e; };
         upd((int)BT, H, D); upd((int)BT, 4 * H, H); upd((int)BT, 4 * H, D); upd(B, 4 * H, H); upd(B, H, Z); upd(B, Z, H);
@@ -277,7 +297,7 @@ extern "C" int shm_vae_plan_create(const shm_vae_config* cfg, int32_t B, int32_t
         p->narrow_scratch = take(narrow_tn_scratch_elems(4 * H, D));
         p->narrow_scratch2 = take(narrow_tn_scratch_elems(H, D));
         p->gemm_partial = take(gp > 0 ? gp : 1);
-        if (bf && L == 2) {
+        if (bf && !sp && L == 2) {
             size_t eb = gemm_tn_bf16_partial_elems((int)(qt * SHM_WPT * T), 4 * H, H, 1);    // encoder layer 0: dW_hh (+ the 16-column dW_ih)
             const size_t eb2 = gemm_tn_bf16_partial_elems((int)(qt * SHM_WPT * T), 4 * H, H, 2);  // decoder layer 0: dW_ih and dW_hh
             if (eb2 > eb) eb = eb2;
@@ -312,7 +332,8 @@ extern "C" int shm_vae_pack_weights(shm_vae_plan* p, const float* params, void* 
     SHM_REQUIRE((reinterpret_cast<uintptr_t>(params) & 15) == 0, SHM_EINVAL, "pack_weights: params must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const int H = p->cfg.hidden_dim, L = p->cfg.num_layers;
-    if (p->cfg.precision == SHM_PREC_BF16) {          // bf16 path: every re-layout, the flat copy and the state words in one launch
+    const bool sp = p->cfg.precision == SHM_PREC_SPLIT;
+    if (p->cfg.precision == SHM_PREC_BF16 || sp) {    // bf16 / split paths: every re-layout, the flat copy and the state words in one launch
         SHM_REQUIRE(p->n_params < ((int64_t)1 << 31), SHM_EINVAL, "pack_weights: parameter count exceeds 2^31");
         PackJobs jobs;
         jobs.n = 0;
@@ -331,9 +352,17 @@ extern "C" int shm_vae_pack_weights(shm_vae_plan* p, const float* params, void* 
                 add(params + li.b_ih, params + li.b_hh, at<float>(ws, li.bsum), 2, 0);
                 add(params + li.w_ih, nullptr, at<bf16_t>(ws, li.Wx), 0, li.In);
                 add(params + li.w_hh, nullptr, at<bf16_t>(ws, li.Wh), 0, H);
+                if (sp) {
+                    add(params + li.w_ih, nullptr, at<bf16_t>(ws, li.Wx_lo), 5, li.In);
+                    add(params + li.w_hh, nullptr, at<bf16_t>(ws, li.Wh_lo), 5, H);
+                }
                 if (p->training) {
                     add(params + li.w_hh, nullptr, at<bf16_t>(ws, li.WhT), 1, H);
                     if (l > 0) add(params + li.w_ih, nullptr, at<bf16_t>(ws, li.WxT), 1, li.In);
+                    if (sp) {
+                        add(params + li.w_hh, nullptr, at<bf16_t>(ws, li.WhT_lo), 6, H);
+                        if (l > 0) add(params + li.w_ih, nullptr, at<bf16_t>(ws, li.WxT_lo), 6, li.In);
+                    }
                 }
             }
         if ((rc = launch_pack_all(jobs, s))) return rc;
@@ -434,22 +463,73 @@ extern "C" int shm_vae_forward(shm_vae_plan* p, const float* x, const float* eps
         }
         return SHM_OK;
     };
+    // split-precision path: per layer [time-parallel input projection ->] recurrence with W_hh hi / lo in registers (lstm_sp.hip)
+    const bool sp = c.precision == SHM_PREC_SPLIT;
+    auto run_stack_sp = [&](LayerInst* st, const float* in0, uint32_t stack, float* h_last) -> int {
+        const int qt = ceil_div(B, SHM_WPT);
+        for (int l = 0; l < L; ++l) {
+            const LayerInst& li = st[l];
+            const char* sn = stack == 0 ? "enc" : "dec";
+            char nm[32];
+            LstmFwdArgsS a;
+            memset(&a, 0, sizeof(a));
+            a.Wh_hi = at<bf16_t>(ws, li.Wh); a.Wh_lo = at<bf16_t>(ws, li.Wh_lo);
+            a.h_hi = at<bf16_t>(ws, li.h_seq); a.h_lo = at<bf16_t>(ws, li.h_lo);
+            a.h_last = (l == L - 1) ? h_last : nullptr;
+            a.rec4 = save ? at<float>(ws, li.saved) : nullptr; a.rec2 = save ? at<float>(ws, li.saved_c) : nullptr;
+            a.B = B; a.T = T; a.In = li.In;
+            if (l == 0 && !li.in_const) {
+                a.mode = 2; a.x = in0; a.Wx_hi = at<bf16_t>(ws, li.Wx); a.Wx_lo = at<bf16_t>(ws, li.Wx_lo); a.bias = at<float>(ws, li.bsum);
+                if (save) { a.x_hi = at<bf16_t>(ws, p->x_tb); a.x_lo = at<bf16_t>(ws, p->x_tb_lo); }
+            } else {
+                XprojArgsS xa;
+                memset(&xa, 0, sizeof(xa));
+                xa.W_hi = at<bf16_t>(ws, li.Wx); xa.W_lo = at<bf16_t>(ws, li.Wx_lo); xa.bias = at<float>(ws, li.bsum);
+                xa.out = at<float>(ws, li.xproj);
+                if (li.in_const) {        // decoder layer 0: one projection per window (temporal_vae.py:68 repeats h0 over T)
+                    int r = launch_split_planes(in0, (size_t)B * H, (size_t)qt * SHM_WPT * H, at<bf16_t>(ws, p->h0_bf), at<bf16_t>(ws, p->h0_lo), s);
+                    if (r) return r;
+                    xa.in_hi = at<bf16_t>(ws, p->h0_bf); xa.in_lo = at<bf16_t>(ws, p->h0_lo); xa.rows = qt * SHM_WPT;
+                    a.mode = 1;
+                } else {
+                    xa.in_hi = at<bf16_t>(ws, st[l - 1].h_seq); xa.in_lo = at<bf16_t>(ws, st[l - 1].h_lo); xa.rows = qt * SHM_WPT * T;
+                    xa.drop_p = drop; xa.drop_seed = drop_seed; xa.drop_stack = stack;
+                    if (drop > 0.f) { xa.xd_hi = at<bf16_t>(ws, li.xdrop); xa.xd_lo = at<bf16_t>(ws, li.xdrop_lo); }
+                    a.mode = 0;
+                }
+                snprintf(nm, sizeof(nm), "xproj.%s%d", sn, l);
+                KernelTimer kt(nm, s);
+                int r = launch_xproj_sp(H, xa, s);
+                if (r) return r;
+                a.xproj = at<float>(ws, li.xproj);
+            }
+            snprintf(nm, sizeof(nm), "lstm_fwd.%s%d", sn, l);
+            KernelTimer kt(nm, s);
+            int r = launch_lstm_fwd_sp(H, a, s);
+            if (r) return r;
+        }
+        return SHM_OK;
+    };
     const float* prm = at<float>(ws, p->params_copy);
-    if ((rc = run_stack(p->enc, x, 0, at<float>(ws, p->h_last)))) return rc;
+    if (sp) { if ((rc = run_stack_sp(p->enc, x, 0, at<float>(ws, p->h_last)))) return rc; }
+    else if ((rc = run_stack(p->enc, x, 0, at<float>(ws, p->h_last)))) return rc;
     {
         KernelTimer kt("head_fwd", s);
         if ((rc = launch_head_fwd(B, H, Z, c.layer_norm, at<float>(ws, p->h_last), at<float>(ws, p->eps), head_params(p, prm),
                                   head_bufs(p, ws), mu, logvar, s))) return rc;
     }
-    if ((rc = run_stack(p->dec, at<float>(ws, p->h0), 1, nullptr))) return rc;
+    if (sp) { if ((rc = run_stack_sp(p->dec, at<float>(ws, p->h0), 1, nullptr))) return rc; }
+    else if ((rc = run_stack(p->dec, at<float>(ws, p->h0), 1, nullptr))) return rc;
     float* rec = recon ? recon : (p->training ? at<float>(ws, p->recon) : nullptr);
     {
+        const bool tb = c.precision != SHM_PREC_F32;       // tile-blocked bf16 sequences (bf16 and split paths)
         KernelTimer kt("out_fwd", s);
-        if ((rc = launch_out_fwd(B, T, D, H, at<char>(ws, p->dec[L - 1].h_seq), c.precision == SHM_PREC_BF16, prm + p->out_w, prm + p->out_b, x, rec,
+        if ((rc = launch_out_fwd(B, T, D, H, at<char>(ws, p->dec[L - 1].h_seq), tb, prm + p->out_w, prm + p->out_b, x, rec,
                                  at<float>(ws, p->score), s,
-                                 (c.precision == SHM_PREC_BF16 && p->training) ? at<float>(ws, p->d_recon) : nullptr,
-                                 c.precision == SHM_PREC_BF16 ? at<float>(ws, p->score_part) : nullptr,
-                                 c.precision == SHM_PREC_BF16 ? at<unsigned>(ws, p->misc + 320) : nullptr))) return rc;
+                                 (tb && p->training) ? at<float>(ws, p->d_recon) : nullptr,
+                                 tb ? at<float>(ws, p->score_part) : nullptr,
+                                 tb ? at<unsigned>(ws, p->misc + 320) : nullptr,
+                                 sp ? at<char>(ws, p->dec[L - 1].h_lo) : nullptr))) return rc;
     }
     if (score) SHM_HIP_CHECK(hipMemcpyAsync(score, at<float>(ws, p->score), sizeof(float) * B, hipMemcpyDeviceToDevice, s));
     p->recon_ptr = rec;
@@ -483,7 +563,7 @@ extern "C" int shm_vae_loss(shm_vae_plan* p, const float* x, float kl_w, float* 
     SHM_REQUIRE(x && losses, SHM_EINVAL, "loss: x or losses is NULL");
     const shm_vae_config& c = p->cfg;
     if ((rc = launch_vae_loss(p->B, p->T, c.input_dim, c.latent_dim, x, p->recon_ptr, at<float>(ws, p->mu), at<float>(ws, p->lv),
-                              kl_w, c.precision == SHM_PREC_BF16 ? nullptr : at<float>(ws, p->d_recon), at<float>(ws, p->d_mu), at<float>(ws, p->d_lv),
+                              kl_w, c.precision != SHM_PREC_F32 ? nullptr : at<float>(ws, p->d_recon), at<float>(ws, p->d_mu), at<float>(ws, p->d_lv),
                               at<float>(ws, p->score), losses, (hipStream_t)stream))) return rc;
     p->loss_done = true;
     return SHM_OK;
@@ -518,12 +598,17 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
     float* cs = at<float>(ws, p->colsum_scratch);
     const HeadBufs hb = head_bufs(p, ws);
 
-    const bool bf = c.precision == SHM_PREC_BF16;
+    const bool sp = c.precision == SHM_PREC_SPLIT;
+    const bool bf = c.precision == SHM_PREC_BF16 || sp;
     // wide products on bf16 operands: dW_ih = dpre^T x_in (dropout re-applied) and dW_hh = dpre^T h_{t-1} in ONE launch (A read once)
+    // lo planes of the split path: {A, Bin, Bh, Bx}
+    struct LoPlanes { const void* A; const void* Bin; const void* Bh; const void* Bx; };
     auto gemm_bf = [&](const void* A, int M, const void* Bin, float* Cin, float dp, uint32_t stack, const void* Bh, float* Chh, int R,
-                       ReduceJobs* defer = nullptr, float* part = nullptr, const void* Bx = nullptr, float* Cx = nullptr) -> int {
+                       ReduceJobs* defer = nullptr, float* part = nullptr, const void* Bx = nullptr, float* Cx = nullptr,
+                       const LoPlanes* lo = nullptr) -> int {
         GemmTnArgsB g;
         memset(&g, 0, sizeof(g));
+        if (lo) { g.nseg = 3; g.A_lo = lo->A; g.Bx_lo = lo->Bx; if (Bin) { g.Bm_lo = lo->Bin; g.Bm2_lo = lo->Bh; } else g.Bm_lo = lo->Bh; }
         g.Bx = Bx; g.Cx = Cx; g.Nx = D;
         if (dp < 0.f) { g.bcast_T = T; dp = 0.f; }      // dp < 0 marks "Bin holds one row per window"
         g.A = A; g.lda = M; g.ldb = H; g.R = R; g.M = M; g.N = H; g.shift_rows = SHM_WPT;
@@ -547,13 +632,14 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
 
     // output layer (temporal_vae.py:70): dW_out[d][k] = sum_r d_recon[r][d] h[r][k]
     const void* h_top = at<char>(ws, p->dec[L - 1].h_seq);
-    const bool pair_bwd = bf && L == 2 && pair_launch_enabled();
+    const bool pair_bwd = bf && !sp && L == 2 && pair_launch_enabled();
     ReduceJobs rjobs;                    // pair path: every reduction of a stack in ONE launch at the end of the stack
     rjobs.n = 0;
     {
         KernelTimer kt("dw_gemm.out", s);
         if ((rc = launch_narrow_tn(h_top, bf ? 1 : 0, H, H, d_recon, D, bf ? ceil_div(B, SHM_WPT) * SHM_WPT * T : BT, grads + p->out_w, 0, grads + p->out_b,
-                                   at<float>(ws, p->narrow_scratch2), s, bf ? T : 0, bf ? B : 0, pair_bwd ? &rjobs : nullptr))) return rc;
+                                   at<float>(ws, p->narrow_scratch2), s, bf ? T : 0, bf ? B : 0, pair_bwd ? &rjobs : nullptr,
+                                   sp ? at<char>(ws, p->dec[L - 1].h_lo) : nullptr))) return rc;
     }
 
     auto run_stack_bwd = [&](LayerInst* st, uint32_t stack, const float* x0, bool is_dec) -> int {
@@ -607,6 +693,63 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
             if (defer) return reduce_jobs_add(*defer, tsum, B, (size_t)G, (size_t)G, grads + st[l].b_ih, grads + st[l].b_hh);
             return launch_reduce_partials(tsum, B, (size_t)G, grads + st[l].b_ih, grads + st[l].b_hh, s);
         };
+        if (sp) {
+            bf16_t* dph = at<bf16_t>(ws, p->dpre_seq); bf16_t* dpl = at<bf16_t>(ws, p->dpre_lo);
+            const char* sn = stack == 0 ? "enc" : "dec";
+            for (int l = L - 1; l >= 0; --l) {
+                char nm[32];
+                LstmBwdArgsS a;
+                memset(&a, 0, sizeof(a));
+                a.rec4 = at<float>(ws, st[l].saved); a.rec2 = at<float>(ws, st[l].saved_c);
+                if (l == L - 1) {
+                    if (is_dec) { a.dy = d_recon; a.Wout = prm + p->out_w; a.Dy = D; }
+                    else a.dh_last = hb.dh_last;
+                } else a.dh_seq = dx_seq;
+                a.WhT_hi = at<bf16_t>(ws, st[l].WhT); a.WhT_lo = at<bf16_t>(ws, st[l].WhT_lo);
+                a.dpre_hi = dph; a.dpre_lo = dpl; a.dpre_tsum = dpre_tsum; a.B = B; a.T = T;
+                int r;
+                {
+                    snprintf(nm, sizeof(nm), "lstm_bwd.%s%d", sn, l);
+                    KernelTimer kt(nm, s);
+                    r = launch_lstm_bwd_sp(H, a, s);
+                }
+                if (r) return r;
+                if (l > 0) {              // gradient on the layer below's h_t, all steps at once
+                    DxArgsS da;
+                    memset(&da, 0, sizeof(da));
+                    da.dpre_hi = dph; da.dpre_lo = dpl; da.WxT_hi = at<bf16_t>(ws, st[l].WxT); da.WxT_lo = at<bf16_t>(ws, st[l].WxT_lo);
+                    da.dx = dx_seq; da.rows = Rt; da.drop_p = drop; da.drop_seed = p->drop_seed; da.drop_stack = stack;
+                    snprintf(nm, sizeof(nm), "dx_gemm.%s%d", sn, l);
+                    KernelTimer kt(nm, s);
+                    if ((r = launch_dx_sp(H, da, s))) return r;
+                }
+                snprintf(nm, sizeof(nm), "dw_gemm.%s%d", sn, l);
+                KernelTimer kt(nm, s);
+                LoPlanes lo;
+                lo.A = dpl; lo.Bh = at<char>(ws, st[l].h_lo); lo.Bin = nullptr; lo.Bx = nullptr;
+                if (l > 0) {
+                    const bool dr = drop > 0.f;
+                    const void* xin = dr ? at<char>(ws, st[l].xdrop) : at<char>(ws, st[l - 1].h_seq);
+                    lo.Bin = dr ? at<char>(ws, st[l].xdrop_lo) : at<char>(ws, st[l - 1].h_lo);
+                    if ((r = gemm_bf(dph, G, xin, grads + st[l].w_ih, 0.f, stack, at<char>(ws, st[l].h_seq), grads + st[l].w_hh, Rt, nullptr, nullptr,
+                                     nullptr, nullptr, &lo))) return r;
+                } else if (st[l].in_const) {
+                    if ((r = gemm_bf(dph, G, nullptr, nullptr, 0.f, 0, at<char>(ws, st[l].h_seq), grads + st[l].w_hh, Rt, nullptr, nullptr,
+                                     nullptr, nullptr, &lo))) return r;
+                    // dW_ih = (sum_t dpre_t)^T h0: B rows, exact fp32 (temporal_vae.py:68 repeats h0, so the T products collapse)
+                    if ((r = gemm(dpre_tsum, G, G, hb.h0, H, H, B, grads + st[l].w_ih, 0, 0, 0.f, 0))) return r;
+                } else {
+                    const bool xfuse = H == 128;      // dW_ih = dpre^T x as a 16-column third product of the same launch
+                    lo.Bx = at<char>(ws, p->x_tb_lo);
+                    if ((r = gemm_bf(dph, G, nullptr, nullptr, 0.f, 0, at<char>(ws, st[l].h_seq), grads + st[l].w_hh, Rt, nullptr, nullptr,
+                                     xfuse ? at<char>(ws, p->x_tb) : nullptr, xfuse ? grads + st[l].w_ih : nullptr, &lo))) return r;
+                    if (!xfuse && (r = launch_narrow_tn(dph, 1, G, G, x0, D, Rt, grads + st[l].w_ih, 1, nullptr, at<float>(ws, p->narrow_scratch), s, T, B,
+                                                        nullptr, dpl))) return r;
+                }
+                if ((r = launch_reduce_partials(dpre_tsum, B, (size_t)G, grads + st[l].b_ih, grads + st[l].b_hh, s))) return r;
+            }
+            return SHM_OK;
+        }
         if (bf && L == 2 && pair_launch_enabled()) {
             // both layers in one launch (layer 0 forms dx itself, a few steps behind layer 1); layer 0 keeps the primary
             // dpre / tsum buffers because the head reads decoder layer 0's sum_t dpre

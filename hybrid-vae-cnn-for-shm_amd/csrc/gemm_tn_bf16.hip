@@ -46,6 +46,11 @@ __global__ void __launch_bounds__(256) gemm_tn_bf16_kernel(GemmTnArgsB a, int ti
     const int kb = tile / (tiles_m * tiles_n), tmn = tile - kb * tiles_m * tiles_n, tm = tmn / tiles_n, tn = tmn - tm * tiles_n;
     const int m0 = tm * MT, n0 = tn * NT;
     const bf16_t* Bm = reinterpret_cast<const bf16_t*>(kb == 0 ? a.Bm : a.Bm2);
+    const bf16_t* const A_hi = A;
+    const bf16_t* const A_lo = reinterpret_cast<const bf16_t*>(a.A_lo);
+    const bf16_t* const B_hi = Bm;
+    const bf16_t* const B_lo = reinterpret_cast<const bf16_t*>(kb == 0 ? a.Bm_lo : a.Bm2_lo);
+    const int nseg = a.nseg > 1 ? 3 : 1;                 // split-precision operands: (A_hi,B_hi), (A_hi,B_lo), (A_lo,B_hi) over the same rows
     const int shift_T = kb == 0 ? a.shift_T : a.shift_T2;
     const float drop_p = kb == 0 ? a.drop_p : 0.f;
     const int r_begin = split * rows_per_split, r_end = min(a.R, r_begin + rows_per_split);
@@ -63,7 +68,11 @@ __global__ void __launch_bounds__(256) gemm_tn_bf16_kernel(GemmTnArgsB a, int ti
 
     // staging: 64 rows x 128 cols = 1024 chunks of 16 B per operand, 4 per thread; chunk e -> (row e/16, cols 8*(e%16)..)
     bf16x8 ra[4], rb[4];
-    auto load_stage = [&](int r0) {
+    const int nst = (r_end - r_begin + KC - 1) / KC, total = nst * nseg;
+    auto load_stage = [&](int k) {
+        const int seg = k / nst, r0 = r_begin + (k - seg * nst) * KC;
+        A = seg == 2 ? A_lo : A_hi;
+        Bm = seg == 1 ? B_lo : B_hi;
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int e = tid + it * 256, row = e >> 4, c8 = (e & 15) * 8, r = r0 + row;
@@ -98,11 +107,11 @@ __global__ void __launch_bounds__(256) gemm_tn_bf16_kernel(GemmTnArgsB a, int ti
     // transpose-read addresses: lane 4q'+p of a 16-lane group supplies row q', columns 4p..4p+3 of the 4x16 block
     const int tr_row = 8 * g + qq, tr_col = 4 * pp;
 
-    load_stage(r_begin);
-    for (int r0 = r_begin; r0 < r_end; r0 += KC) {
+    load_stage(0);
+    for (int k = 0; k < total; ++k) {
         store_stage();
         __syncthreads();
-        if (r0 + KC < r_end) load_stage(r0 + KC);            // next stage in flight while this one is consumed
+        if (k + 1 < total) load_stage(k + 1);                // next stage in flight while this one is consumed
 #pragma unroll
         for (int ks = 0; ks < KC / 32; ++ks) {
             bf16x8 af[4], bfr[4];
@@ -174,7 +183,7 @@ __global__ void __launch_bounds__(512) gemm_tn_bf16_v2_kernel(GemmTnArgsB a, int
     const int m0 = tm * V2_MT;
     const int r_begin = split * rows_per_split, r_end = min(a.R, r_begin + rows_per_split);
     const int nst = (r_end - r_begin + V2_KC - 1) / V2_KC;
-    const bf16_t* A = reinterpret_cast<const bf16_t*>(a.A);
+    const int nseg = a.nseg > 1 ? 3 : 1, total = nst * nseg;   // split-precision operands: plane pairs (hi,hi), (hi,lo), (lo,hi) over the same rows
     const bf16_t* zeros = reinterpret_cast<const bf16_t*>(a.zeros);
 
     // ---- per-lane LDS-DMA sources.  A: instruction j = 2w + i covers stage rows 2j, 2j+1 (512 B each): lane -> row l>>5, chunk l&31
@@ -196,7 +205,10 @@ __global__ void __launch_bounds__(512) gemm_tn_bf16_v2_kernel(GemmTnArgsB a, int
     }
     auto issue = [&](int k) {                            // stage k -> ring slot k % NBUF (always issued: the counts stay static)
         char* buf = smem + (k & (V2_NBUF - 1)) * ST_BYTES;
-        const int r0 = r_begin + k * V2_KC;
+        const int seg = k / nst;                          // >= nseg for the over-issued tail stages: every row reads the zero line
+        const int r0 = seg < nseg ? r_begin + (k - seg * nst) * V2_KC : r_end;
+        const bf16_t* A = reinterpret_cast<const bf16_t*>(seg == 2 ? a.A_lo : a.A);
+        const bool blo = seg == 1;
 #pragma unroll
         for (int i = 0; i < GL_A; ++i) {
             const int r = r0 + a_row[i];
@@ -207,7 +219,7 @@ __global__ void __launch_bounds__(512) gemm_tn_bf16_v2_kernel(GemmTnArgsB a, int
         for (int i = 0; i < GL_B; ++i) {
             const int r = r0 + b_row[i];
             const bool second = NB == 2 ? b_prod[i] == 1 : false;
-            const bf16_t* base = reinterpret_cast<const bf16_t*>(second ? a.Bm2 : a.Bm);
+            const bf16_t* base = reinterpret_cast<const bf16_t*>(second ? (blo ? a.Bm2_lo : a.Bm2) : (blo ? a.Bm_lo : a.Bm));
             const int sh = second ? a.shift_T2 : a.shift_T;
             bool ok = r < r_end;
             int rr = ok ? r : r_begin;
@@ -219,7 +231,7 @@ __global__ void __launch_bounds__(512) gemm_tn_bf16_v2_kernel(GemmTnArgsB a, int
         if constexpr (XP) {
             if (w == 0) {                                 // 32 rows x 32 B: lane -> row l>>1, half l&1
                 const int r = r0 + (lane >> 1);
-                const bf16_t* src = r < r_end ? reinterpret_cast<const bf16_t*>(a.Bx) + (size_t)r * 16 + (lane & 1) * 8 : zeros;
+                const bf16_t* src = r < r_end ? reinterpret_cast<const bf16_t*>(blo ? a.Bx_lo : a.Bx) + (size_t)r * 16 + (lane & 1) * 8 : zeros;
                 __builtin_amdgcn_global_load_lds((gbl_cvoid*)src, (lds_void*)(buf + A_BYTES + B_BYTES), 16, 0, 0);
             }
         }
@@ -287,7 +299,7 @@ __global__ void __launch_bounds__(512) gemm_tn_bf16_v2_kernel(GemmTnArgsB a, int
     };
 
     issue(0); issue(1); issue(2);
-    for (int k = 0; k < nst; ++k) {
+    for (int k = 0; k < total; ++k) {
         // stage k has landed; k+1, k+2 stay in flight (2 x LDS-DMA instructions per wave and stage)
         if (NB == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if (XP && w == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -369,6 +381,8 @@ int launch_gemm_tn_bf16(const GemmTnArgsB& a, hipStream_t s, ReduceJobs* defer) 
     SHM_REQUIRE((a.M & 7) == 0 && (a.N & 7) == 0 && (a.lda & 7) == 0 && (a.ldb & 7) == 0, SHM_EINVAL,
                 "gemm_tn_bf16: M, N, lda, ldb must be multiples of 8 (got %d %d %d %d)", a.M, a.N, a.lda, a.ldb);
     SHM_REQUIRE(a.NB == 1 || (a.Bm2 && a.C2), SHM_EINVAL, "gemm_tn_bf16: second operand missing");
+    SHM_REQUIRE(a.nseg <= 1 || (a.A_lo && a.Bm_lo && (a.NB == 1 || a.Bm2_lo) && (!a.Bx || a.Bx_lo) && !(a.drop_p > 0.f)), SHM_EINVAL,
+                "gemm_tn_bf16: split-precision operands need every lo plane (and no in-kernel dropout)");
     const bool v2 = v2_ok(a);
     SHM_REQUIRE(a.bcast_T == 0 || v2, SHM_EINVAL, "gemm_tn_bf16: the per-window operand needs the H = 128 kernel");
     const Geo g = v2 ? geometry_v2(a.R, a.M) : geometry(a.R, a.M, a.N, a.NB);

@@ -67,7 +67,7 @@ int launch_head_grads(int B, int H, int Z, int layer_norm, const HeadBufs& hb, f
 // h_bf16: h_seq is bf16 in tile-blocked row order (row of (b,t) = ((b/16)*T + t)*16 + b%16); else fp32 natural [B,T,H]
 int launch_out_fwd(int B, int T, int D, int H, const void* h_seq, int h_bf16, const float* Wout, const float* bout, const float* x,
                    float* recon, float* score, hipStream_t s, float* d_recon = nullptr, float* score_part = nullptr,
-                   unsigned* tile_cnt = nullptr);   // bf16: score_part [4][ceil(B/4)*4] + tile_cnt [ceil(B/4)] (zeroed) let several workgroups share a tile   // d_recon (bf16 path, optional): 2 (recon - x) / (B T D)
+                   unsigned* tile_cnt = nullptr, const void* h_lo = nullptr);   // h_lo: split-precision path, h_seq / h_lo = the hi / lo planes   // bf16: score_part [4][ceil(B/4)*4] + tile_cnt [ceil(B/4)] (zeroed) let several workgroups share a tile   // d_recon (bf16 path, optional): 2 (recon - x) / (B T D)
 int launch_vae_loss(int B, int T, int D, int Z, const float* x, const float* recon, const float* mu, const float* lv,
                     float kl_w, float* d_recon, float* d_mu, float* d_lv, float* score, float* losses, hipStream_t s);
 
@@ -107,7 +107,8 @@ size_t colsum_scratch_elems(int R, int N);
 // tile_T > 0: A's rows are tile-blocked (row r' = (tile*tile_T + t)*16 + j) while Bn is natural [B, tile_T, N]; rows of windows
 // >= tile_B are padding and skipped.
 int launch_narrow_tn(const void* A, int a_bf16, int lda, int M, const float* Bn, int N, int R, float* out, int trans_out,
-                     float* bsum_out, float* scratch, hipStream_t s, int tile_T = 0, int tile_B = 0, ReduceJobs* defer = nullptr);
+                     float* bsum_out, float* scratch, hipStream_t s, int tile_T = 0, int tile_B = 0, ReduceJobs* defer = nullptr,
+                     const void* A_lo = nullptr);        // A_lo: lo plane of a split-precision A (the product uses hi + lo)
 size_t narrow_tn_scratch_elems(int M, int N);
 // out[i] (and out1[i]) = sum_p partial[p*n + i], p < nparts (fixed order)
 int launch_reduce_partials(const float* partial, int nparts, size_t n, float* out0, float* out1, hipStream_t s);
@@ -179,13 +180,71 @@ struct GemmTnArgsB {
     float* partial; size_t partial_elems;
     const void* Bx; float* Cx; int Nx;   // optional third product sharing A (H = 128 kernel, NB == 1): Bx [R, 16] bf16, Cx [M, Nx] = A^T Bx[:, :Nx]
     const void* zeros;             // >= 16 zero bytes (the H = 128 kernel reads them for rows that must contribute nothing); may be NULL
+    // split-precision operands (nseg = 3): A / Bm / Bm2 / Bx are the HI planes, these the LO planes; the kernel walks its rows three
+    // times — (A, B), (A, B_lo), (A_lo, B) — into one accumulator, i.e. hi*hi + hi*lo + lo*hi in fp32
+    int nseg;
+    const void* A_lo; const void* Bm_lo; const void* Bm2_lo; const void* Bx_lo;
 };
 int launch_gemm_tn_bf16(const GemmTnArgsB& a, hipStream_t s, ReduceJobs* defer = nullptr);
 size_t gemm_tn_bf16_partial_elems(int R, int M, int N, int NB);
 
+// ==== split-precision path (SHM_PREC_SPLIT): every MFMA operand is a bf16 PAIR hi + lo (hi = bf16(x), lo = bf16(x - hi): 16
+// significant bits), products hi*hi + hi*lo + lo*hi (+ lo*lo in the recurrences) accumulate in fp32; cell state, records,
+// gradients and sums stay fp32.  Holds the reference's fp32 results to ~1e-6 at bf16 MFMA rates (lstm_sp.hip).
+// Sequence buffers are two bf16 PLANES (hi, lo) in the tile-blocked row order of the bf16 path.
+struct LstmFwdArgsS {
+    const float* xproj;     // mode 0: W_ih x_t + b for every step, cell order [tile][t][H/16][64] x f32x4 {i,f,g,o};
+                            // mode 1: the same once per window [tile][H/16][64] (constant input: decoder layer 0)
+    const float* x;         // mode 2: fp32 [B,T,In], In <= 16 (encoder layer 0: projected in the kernel)
+    const bf16_t* Wh_hi; const bf16_t* Wh_lo;     // forward fragment order (kernels.hpp: bf16 packing)
+    const bf16_t* Wx_hi; const bf16_t* Wx_lo;     // mode 2
+    const float* bias;                            // mode 2: b_ih + b_hh (modes 0/1: folded into xproj)
+    bf16_t* h_hi; bf16_t* h_lo;                   // [ceil(B/WPT)*T*WPT, H] each
+    float* h_last;                                // [B,H] fp32 or nullptr
+    float* rec4; float* rec2;                     // BPTT records [tile][t][H/16][64] x {i,f,g,o} / {c_{t-1}, tanh c_t}, or nullptr
+    bf16_t* x_hi; bf16_t* x_lo;                   // mode 2, optional: tile-blocked [rows,16] copies of x (dW_ih product)
+    int B, T, In, mode;
+};
+int launch_lstm_fwd_sp(int H, const LstmFwdArgsS& a, hipStream_t s);
+
+struct LstmBwdArgsS {
+    const float* rec4; const float* rec2;
+    const float* dh_seq;    // fragment order (dx of the layer above, written by launch_dx_sp) or nullptr
+    const float* dy; const float* Wout; const float* dh_last;
+    const bf16_t* WhT_hi; const bf16_t* WhT_lo;   // backward fragment order
+    bf16_t* dpre_hi; bf16_t* dpre_lo;             // [rows, 4H] planes
+    float* dpre_tsum;       // [B,4H]
+    int B, T, Dy;
+};
+int launch_lstm_bwd_sp(int H, const LstmBwdArgsS& a, hipStream_t s);
+
+// time-parallel halves: out = W_ih in + b (cell order, see LstmFwdArgsS::xproj) and dx = dpre W_ih (fragment order)
+struct XprojArgsS {
+    const bf16_t* in_hi; const bf16_t* in_lo;     // [rows, H] planes (rows = tile-blocked (tile, t, window); t_per_tile steps per tile)
+    const bf16_t* W_hi; const bf16_t* W_lo;       // forward fragment order of W_ih [4H, H]
+    const float* bias;                            // [4H]
+    float* out;                                   // cell order
+    bf16_t* xd_hi; bf16_t* xd_lo;                 // dropout: the masked + rescaled input planes (operand of the dW_ih GEMM)
+    int rows;
+    float drop_p; uint64_t drop_seed; uint32_t drop_stack;
+};
+int launch_xproj_sp(int H, const XprojArgsS& a, hipStream_t s);
+struct DxArgsS {
+    const bf16_t* dpre_hi; const bf16_t* dpre_lo; // [rows, 4H]
+    const bf16_t* WxT_hi; const bf16_t* WxT_lo;   // backward fragment order of W_ih
+    float* dx;                                    // fragment order [rows/16][H/16][64] x f32x4
+    int rows;
+    float drop_p; uint64_t drop_seed; uint32_t drop_stack;
+};
+int launch_dx_sp(int H, const DxArgsS& a, hipStream_t s);
+// fp32 [n_valid] -> bf16 planes hi, lo of n >= n_valid elements (the tail is zero-filled: padding windows of the last tile)
+int launch_split_planes(const float* src, size_t n_valid, size_t n, bf16_t* hi, bf16_t* lo, hipStream_t s);
+
 // all bf16 re-layouts + bias sums of one parameter update in a single launch
-struct PackJob { const float* src; const float* src2; void* dst; int kind, H, K; };   // kind 0: fwd operand (K = in width), 1: bwd operand (K = M), 2: bias sum, 3: copy K floats, 4: zero K dwords
-struct PackJobs { PackJob job[24]; int n; };
+// kind 0: fwd operand (K = in width), 1: bwd operand (K = M), 2: bias sum, 3: copy K floats, 4: zero K dwords,
+// 5 / 6: the LO parts (bf16(w - bf16(w))) of kinds 0 / 1
+struct PackJob { const float* src; const float* src2; void* dst; int kind, H, K; };
+struct PackJobs { PackJob job[48]; int n; };
 int launch_pack_all(const PackJobs& jobs, hipStream_t s);
 int launch_pack_fwd_bf16(const float* W, int H, int K, bf16_t* dst, hipStream_t s);
 int launch_pack_bwd_bf16(const float* W, int H, int M, bf16_t* dst, hipStream_t s);

@@ -280,8 +280,10 @@ __global__ void __launch_bounds__(256) out_fwd_kernel(int T, int D, int H, const
 // (4 waves walking 16 groups each with dependent loads took 57 us; the kernel is pure latency).  d_recon (optional) is the
 // gradient of the mean-squared error, 2 (recon - x) / (B T D), written here so that the loss kernel has no pass over [B,T,D].
 constexpr int OUT_WAVES = 8;
-template <int H>
+// SPLIT (split-precision path): h_seq / h_lo are the hi / lo planes and W_out is split the same way: three products per fragment.
+template <int H, bool SPLIT>
 __global__ void __launch_bounds__(64 * OUT_WAVES) out_fwd_mfma_kernel(int B, int T, int D, const bf16_t* __restrict__ h_seq,
+                                                           const bf16_t* __restrict__ h_lo,
                                                            const float* __restrict__ Wout, const float* __restrict__ bout,
                                                            const float* __restrict__ x, float* __restrict__ recon,
                                                            float* __restrict__ score, float* __restrict__ d_recon,
@@ -291,11 +293,15 @@ __global__ void __launch_bounds__(64 * OUT_WAVES) out_fwd_mfma_kernel(int B, int
     __shared__ float red[OUT_WAVES][4][64];
     const float dsc = 2.0f / ((float)B * (float)T * (float)D);
     const int tile = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
-    bf16x8 wf[KS];                      // B operand: lane (q,j) holds W_out[j][8q + 32s .. +7] (zero for j >= D)
+    bf16x8 wf[KS], wfl[SPLIT ? KS : 1];  // B operand: lane (q,j) holds W_out[j][8q + 32s .. +7] (zero for j >= D)
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) wf[s][e] = (bf16_t)(j < D ? Wout[(size_t)j * H + 8 * q + 32 * s + e] : 0.f);
+        for (int e = 0; e < 8; ++e) {
+            const float w = j < D ? Wout[(size_t)j * H + 8 * q + 32 * s + e] : 0.f;
+            wf[s][e] = (bf16_t)w;
+            if constexpr (SPLIT) wfl[s][e] = (bf16_t)(w - (float)wf[s][e]);
+        }
     }
     const float bias = j < D ? bout[j] : 0.f;
     const int n_groups = (T * 4 + 15) / 16;                           // 16-row groups of this tile (4 steps each)
@@ -304,12 +310,13 @@ __global__ void __launch_bounds__(64 * OUT_WAVES) out_fwd_mfma_kernel(int B, int
     const int per_part = (n_groups + nsplit - 1) / nsplit;
     const int g_lo = part * per_part, g_hi = min(n_groups, g_lo + per_part);
     const bf16_t* hb = h_seq + (size_t)tile * T * 4 * H;
+    const bf16_t* hbl = SPLIT ? h_lo + (size_t)tile * T * 4 * H : nullptr;
     float sq[4] = {0.f, 0.f, 0.f, 0.f};
     // GB groups per wave and pass: all their fragment loads (GB x KS x 16 B per lane) are in flight before the first MFMA
-    constexpr int GB = 4;
+    constexpr int GB = SPLIT ? 2 : 4;
     const bf16x8 zero8 = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
     for (int g0 = g_lo + w * GB; g0 < g_hi; g0 += OUT_WAVES * GB) {
-        bf16x8 af[GB][KS];
+        bf16x8 af[GB][KS], al[SPLIT ? GB : 1][KS];
 #pragma unroll
         for (int gi = 0; gi < GB; ++gi) {
             const int row = (g0 + gi) * 16 + j;                       // A operand row supplied by this lane
@@ -317,13 +324,24 @@ __global__ void __launch_bounds__(64 * OUT_WAVES) out_fwd_mfma_kernel(int B, int
             const bf16_t* src = hb + (size_t)(rv ? row : 0) * H + 8 * q;
 #pragma unroll
             for (int s = 0; s < KS; ++s) { const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + 32 * s); af[gi][s] = rv ? v : zero8; }
+            if constexpr (SPLIT) {
+                const bf16_t* srl = hbl + (size_t)(rv ? row : 0) * H + 8 * q;
+#pragma unroll
+                for (int s = 0; s < KS; ++s) { const bf16x8 v = *reinterpret_cast<const bf16x8*>(srl + 32 * s); al[gi][s] = rv ? v : zero8; }
+            }
         }
 #pragma unroll
         for (int gi = 0; gi < GB; ++gi) {
             const int grp = g0 + gi;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < KS; ++s) acc = mfma_bf16_16x16x32(af[gi][s], wf[s], acc);
+            for (int s = 0; s < KS; ++s) {
+                acc = mfma_bf16_16x16x32(af[gi][s], wf[s], acc);
+                if constexpr (SPLIT) {
+                    acc = mfma_bf16_16x16x32(al[gi][s], wf[s], acc);
+                    acc = mfma_bf16_16x16x32(af[gi][s], wfl[s], acc);
+                }
+            }
             const int t = grp * 4 + q;                                // accumulator rows 4q + r: step t, window r
             if (j < D && t < T && grp < g_hi) {
 #pragma unroll
@@ -549,7 +567,7 @@ template <> struct VecLoad<bf16_t, 8> { static __device__ __forceinline__ void l
 
 // CPT columns per thread: 8 (one 16/32-byte vector load per row) for <= 4 channels, 2 for up to 16 channels.
 template <typename TA, int NMAX, int CPT>
-__global__ void __launch_bounds__(256) narrow_tn_kernel(const TA* __restrict__ A, int lda, int M, const float* __restrict__ Bn, int N,
+__global__ void __launch_bounds__(256) narrow_tn_kernel(const TA* __restrict__ A, const TA* __restrict__ A_lo, int lda, int M, const float* __restrict__ Bn, int N,
                                                         int R, float* __restrict__ partial, int with_bsum, int tile_T, int tile_B) {
     extern __shared__ float nred[];                     // [groups][NMAX][M] (+ [groups][NMAX] column sums of Bn)
     const int tpr = M / CPT;                            // threads per row
@@ -580,6 +598,12 @@ __global__ void __launch_bounds__(256) narrow_tn_kernel(const TA* __restrict__ A
             }
             float av[CPT];
             VecLoad<TA, CPT>::ld(A + (size_t)r * lda + m, av);
+            if (A_lo) {                                   // split-precision planes: the value is hi + lo (exact in fp32)
+                float al[CPT];
+                VecLoad<TA, CPT>::ld(A_lo + (size_t)r * lda + m, al);
+#pragma unroll
+                for (int c = 0; c < CPT; ++c) av[c] += al[c];
+            }
 #pragma unroll
             for (int n = 0; n < NMAX; ++n) {
                 if (n < N) {
@@ -670,7 +694,9 @@ __global__ void __launch_bounds__(256) pack_all_kernel(PackJobs jobs) {
     const PackJob jb = jobs.job[blockIdx.y];
     const size_t stride = (size_t)gridDim.x * 256, i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int H = jb.H;
-    if (jb.kind == 0) {            // forward operand, bf16 (layout in kernels.hpp)
+    // kinds 5 / 6: the LO part of the split-precision pair, bf16(w - bf16(w)), in the layout of kinds 0 / 1
+    auto part = [&](float w, bool lo) { const bf16_t hi = (bf16_t)w; return lo ? (bf16_t)(w - (float)hi) : hi; };
+    if (jb.kind == 0 || jb.kind == 5) {            // forward operand, bf16 (layout in kernels.hpp)
         const int K = jb.K, Kp = (K + 31) & ~31, KQ = Kp >> 2, KS = KQ >> 3;
         bf16_t* dst = reinterpret_cast<bf16_t*>(jb.dst);
         for (size_t i = i0; i < (size_t)4 * H * Kp; i += stride) {
@@ -679,9 +705,9 @@ __global__ void __launch_bounds__(256) pack_all_kernel(PackJobs jobs) {
             const int g = r & 3; r >>= 2;
             const int s = r % KS, ht = r / KS;
             const int row = g * H + ht * 16 + (lane & 15), k = (lane >> 4) * KQ + 8 * s + e;
-            dst[i] = (bf16_t)(k < K ? jb.src[(size_t)row * K + k] : 0.f);
+            dst[i] = part(k < K ? jb.src[(size_t)row * K + k] : 0.f, jb.kind == 5);
         }
-    } else if (jb.kind == 1) {     // backward operand (W^T), bf16
+    } else if (jb.kind == 1 || jb.kind == 6) {     // backward operand (W^T), bf16
         const int M = jb.K, KS = H >> 3, Mp = (M + 15) & ~15;
         bf16_t* dst = reinterpret_cast<bf16_t*>(jb.dst);
         for (size_t i = i0; i < (size_t)Mp * 4 * H; i += stride) {
@@ -689,7 +715,7 @@ __global__ void __launch_bounds__(256) pack_all_kernel(PackJobs jobs) {
             const size_t r = i >> 9;
             const int s = r % KS, mt = r / KS;
             const int k = (lane >> 4) * H + 8 * s + e, m = mt * 16 + (lane & 15);
-            dst[i] = (bf16_t)(m < M ? jb.src[(size_t)k * M + m] : 0.f);
+            dst[i] = part(m < M ? jb.src[(size_t)k * M + m] : 0.f, jb.kind == 6);
         }
     } else if (jb.kind == 2) {     // bias sum b_ih + b_hh
         float* dst = reinterpret_cast<float*>(jb.dst);
@@ -740,7 +766,7 @@ int out_fwd_parts(int B, int T) {
     return n == 3 ? 2 : n;
 }
 int launch_out_fwd(int B, int T, int D, int H, const void* h_seq, int h_bf16, const float* Wout, const float* bout, const float* x,
-                   float* recon, float* score, hipStream_t s, float* d_recon, float* score_part, unsigned* tile_cnt) {
+                   float* recon, float* score, hipStream_t s, float* d_recon, float* score_part, unsigned* tile_cnt, const void* h_lo) {
     SHM_REQUIRE(!d_recon || h_bf16, SHM_EINVAL, "out: d_recon is written by the bf16 kernel only");
     SHM_REQUIRE(D <= DMAX && H <= HMAX, SHM_EINVAL, "out: D=%d (<=%d) H=%d unsupported", D, DMAX, H);
     if (h_bf16) {
@@ -748,9 +774,11 @@ int launch_out_fwd(int B, int T, int D, int H, const void* h_seq, int h_bf16, co
         const int parts = (score_part && tile_cnt) ? out_fwd_parts(B, T) : 1;
         const dim3 grid(tiles, parts);
         const bf16_t* hs = (const bf16_t*)h_seq;
-        if (H == 128) SHM_LAUNCH(out_fwd_mfma_kernel<128>, grid, dim3(64 * OUT_WAVES), 0, s, B, T, D, hs, Wout, bout, x, recon, score, d_recon, score_part, tile_cnt);
-        else if (H == 64) SHM_LAUNCH(out_fwd_mfma_kernel<64>, grid, dim3(64 * OUT_WAVES), 0, s, B, T, D, hs, Wout, bout, x, recon, score, d_recon, score_part, tile_cnt);
-        else SHM_LAUNCH(out_fwd_mfma_kernel<32>, grid, dim3(64 * OUT_WAVES), 0, s, B, T, D, hs, Wout, bout, x, recon, score, d_recon, score_part, tile_cnt);
+        const bf16_t* hl = (const bf16_t*)h_lo;
+#define SHM_OUT(HH, SP) SHM_LAUNCH((out_fwd_mfma_kernel<HH, SP>), grid, dim3(64 * OUT_WAVES), 0, s, B, T, D, hs, hl, Wout, bout, x, recon, score, d_recon, score_part, tile_cnt)
+        if (hl) { if (H == 128) SHM_OUT(128, true); else if (H == 64) SHM_OUT(64, true); else SHM_OUT(32, true); }
+        else { if (H == 128) SHM_OUT(128, false); else if (H == 64) SHM_OUT(64, false); else SHM_OUT(32, false); }
+#undef SHM_OUT
     }
     else
         SHM_LAUNCH((out_fwd_kernel<float, false>), dim3(B), dim3(256), 0, s, T, D, H, (const float*)h_seq, Wout, bout, x, recon, score);
@@ -829,7 +857,7 @@ int launch_pack_bwd_f32(const float* W, int H, int M, float* dst, hipStream_t s)
 }
 size_t narrow_tn_scratch_elems(int M, int N) { return (size_t)(NARROW_BLOCKS + 1) * (M * N + N); }
 int launch_narrow_tn(const void* A, int a_bf16, int lda, int M, const float* Bn, int N, int R, float* out, int trans_out,
-                     float* bsum_out, float* scratch, hipStream_t s, int tile_T, int tile_B, ReduceJobs* defer) {
+                     float* bsum_out, float* scratch, hipStream_t s, int tile_T, int tile_B, ReduceJobs* defer, const void* A_lo) {
     const int cpt = N <= 4 ? 8 : 2, nmax = N <= 4 ? 4 : 16;
     SHM_REQUIRE(N >= 1 && N <= 16 && M >= cpt && M <= 512 && M % cpt == 0 && 256 % (M / cpt) == 0 && lda % cpt == 0, SHM_EINVAL,
                 "narrow_tn: unsupported shape M=%d N=%d lda=%d", M, N, lda);
@@ -839,7 +867,7 @@ int launch_narrow_tn(const void* A, int a_bf16, int lda, int M, const float* Bn,
     const int blocks = R < NARROW_BLOCKS * groups * 2 ? ceil_div(R, groups * 2) : NARROW_BLOCKS;
     const int wb = bsum_out ? 1 : 0;
     const size_t stride = (size_t)M * N + (wb ? N : 0);
-#define SHM_NARROW(TA, NM, CP) SHM_LAUNCH((narrow_tn_kernel<TA, NM, CP>), dim3(blocks), dim3(256), lds, s, (const TA*)A, lda, M, Bn, N, R, scratch, wb, tile_T, tile_B)
+#define SHM_NARROW(TA, NM, CP) SHM_LAUNCH((narrow_tn_kernel<TA, NM, CP>), dim3(blocks), dim3(256), lds, s, (const TA*)A, (const TA*)A_lo, lda, M, Bn, N, R, scratch, wb, tile_T, tile_B)
     if (a_bf16) { if (nmax == 4) SHM_NARROW(bf16_t, 4, 8); else SHM_NARROW(bf16_t, 16, 2); }
     else { if (nmax == 4) SHM_NARROW(float, 4, 8); else SHM_NARROW(float, 16, 2); }
 #undef SHM_NARROW

@@ -13,7 +13,8 @@ import os
 # SHM_HIP_LIB: another build of the same library (A/B measurements on one box); the default is the in-tree build
 _LIB_PATH = Path(os.environ.get("SHM_HIP_LIB") or Path(__file__).resolve().parent.parent / "csrc" / "libshm_hip.so")
 
-SHM_PREC_F32, SHM_PREC_BF16 = 0, 1
+SHM_PREC_F32, SHM_PREC_BF16, SHM_PREC_SPLIT = 0, 1, 2
+PRECISIONS = {"fp32": SHM_PREC_F32, "bf16": SHM_PREC_BF16, "split": SHM_PREC_SPLIT}
 
 
 class VaeConfig(C.Structure):

@@ -32,7 +32,9 @@ extern "C" {
 #define SHM_EWORKSPACE   -2   /* workspace too small */
 #define SHM_ESTATE       -3   /* call order violated (e.g. backward without a training forward) */
 
-enum { SHM_PREC_F32 = 0, SHM_PREC_BF16 = 1 };
+/* SHM_PREC_SPLIT: every MFMA operand is a pair of bf16 values hi + lo (16 significant bits), products hi*hi + hi*lo + lo*hi in fp32:
+ * holds the reference's fp32 results to ~1e-6 (the 1e-4 parity bar) at bf16 matrix rates — the fast parity path. */
+enum { SHM_PREC_F32 = 0, SHM_PREC_BF16 = 1, SHM_PREC_SPLIT = 2 };
 
 /* Constructor arguments of TemporalVAE (4DOF/Scripts/Models/temporal_vae.py:14-21; the 1_DOF variant
  * 1_DOF/Scripts/Models/temporal_vae.py:11 has no LayerNorm -> layer_norm = 0). */
@@ -42,7 +44,7 @@ typedef struct shm_vae_config {
     int32_t hidden_dim;    /* H  in {32, 64, 128} */
     int32_t num_layers;    /* L  in {1, 2} */
     int32_t layer_norm;    /* 1 = nn.LayerNorm on h_n[-1] (eps 1e-5, biased variance) */
-    int32_t precision;     /* SHM_PREC_F32: fp32 MFMA parity path; SHM_PREC_BF16: bf16 MFMA, fp32 accumulate/state */
+    int32_t precision;     /* SHM_PREC_F32: exact-fp32 MFMA; SHM_PREC_BF16: bf16 MFMA, fp32 accumulate/state; SHM_PREC_SPLIT: bf16 hi+lo pairs */
     float   dropout;       /* nn.LSTM inter-layer dropout p (train mode, L > 1 only) */
 } shm_vae_config;
 

@@ -33,3 +33,15 @@ def split_prefix(d, prefix):
 @pytest.fixture
 def golden():
     return load_golden
+
+
+def record_parity(test, case, errors):
+    """Append the measured errors of a parity case to gpurun_out/parity_errors.jsonl (scratch; the round's summary is
+    aggregated from it into profiles/rNN_parity_errors.json by tools/collect_parity.py)."""
+    out = ROOT / "gpurun_out"
+    try:
+        out.mkdir(exist_ok=True)
+        with open(out / "parity_errors.jsonl", "a") as f:
+            f.write(json.dumps({"test": test, "case": case, "errors": errors}) + "\n")
+    except OSError:
+        pass

@@ -11,11 +11,13 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, split_prefix
+from conftest import load_golden, record_parity, split_prefix
 
 pytestmark = pytest.mark.gpu
 
-TOL = 1e-4            # north_star tolerance (fp32 path)
+TOL = 1e-4            # north_star tolerance: held by BOTH parity-grade paths
+# "fp32": exact-f32 MFMA (bitwise an fmaf chain); "split": bf16 hi+lo operand pairs, fp32 accumulate (the fast parity path)
+PRECS = ["fp32", "split"]
 
 
 @contextmanager
@@ -35,10 +37,10 @@ def inject_eps(eps_list):
         torch.randn_like = orig
 
 
-def build_module(cfg, params, dropout=None):
+def build_module(cfg, params, dropout=None, precision="fp32"):
     from Scripts.Models.temporal_vae import TemporalVAE
     m = TemporalVAE(cfg["input_dim"], cfg["latent_dim"], cfg["hidden_dim"], cfg["num_layers"],
-                    cfg["dropout"] if dropout is None else dropout, layer_norm=cfg["layer_norm"])
+                    cfg["dropout"] if dropout is None else dropout, layer_norm=cfg["layer_norm"], precision=precision)
     missing = m.load_state_dict({k: torch.tensor(v) for k, v in params.items()}, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
     return m.cuda()
@@ -52,10 +54,11 @@ def maxdiff(a, b):
 FWD = ["vae_fwd_mini", "vae_fwd_1dof", "vae_fwd_openlab", "vae_fwd_ref_h128", "vae_fwd_ns_h128"]
 
 
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("name", FWD)
-def test_forward_matches_reference_goldens(name):
+def test_forward_matches_reference_goldens(name, prec):
     g = load_golden(name)
-    m = build_module(g["cfg"], split_prefix(g, "p.")).eval()
+    m = build_module(g["cfg"], split_prefix(g, "p."), precision=prec).eval()
     x = torch.tensor(g["x"]).cuda()
     with torch.no_grad(), inject_eps([torch.tensor(g["eps"])]):
         recon, mu, lv = m(x)
@@ -63,7 +66,8 @@ def test_forward_matches_reference_goldens(name):
         score = m.score(x)
     d = dict(recon=maxdiff(recon, g["recon"]), mu=maxdiff(mu, g["mu"]), logvar=maxdiff(lv, g["logvar"]),
              score=maxdiff(score, g["score"]))
-    print(name, json.dumps(d))
+    print(name, prec, json.dumps(d))
+    record_parity("forward_goldens", f"{name}/{prec}", d)
     assert max(d.values()) < TOL, d
 
 
@@ -78,14 +82,15 @@ def _grad_report(named_grads, ref):
 TRAIN = ["vae_train_mini", "vae_train_1dof", "vae_train_openlab", "vae_train_ns_h128"]
 
 
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("name", TRAIN)
-def test_dropin_train_loop_matches_reference(name):
+def test_dropin_train_loop_matches_reference(name, prec):
     """The reference's own loop (03_train_vae.py:260-271) with torch's loss ops, clip_grad_norm_ and torch.optim.Adam
     around the drop-in module: autograd reaches the HIP backward through VAEFunction."""
     import torch.nn.functional as F
     g = load_golden(name)
     cfg = g["cfg"]
-    m = build_module(cfg, split_prefix(g, "p0."), dropout=0.0).train()
+    m = build_module(cfg, split_prefix(g, "p0."), dropout=0.0, precision=prec).train()
     opt = torch.optim.Adam(m.parameters(), lr=cfg["lr"], weight_decay=cfg["wd"])
     n = cfg["n_steps"]
     for s in range(n):
@@ -99,7 +104,8 @@ def test_dropin_train_loop_matches_reference(name):
         loss.backward()
         if s == 0:
             rep = _grad_report({k: p.grad for k, p in m.named_parameters()}, split_prefix(g, "g0."))
-            print(name, "grad rel err", json.dumps({k: round(v, 7) for k, v in rep.items()}))
+            print(name, prec, "grad rel err", json.dumps({k: round(v, 7) for k, v in rep.items()}))
+            record_parity("dropin_train", f"{name}/{prec}", {"grad_worst_of_max": max(rep.values()), "recon": maxdiff(xhat, g["recon0"])})
             assert maxdiff(xhat, g["recon0"]) < TOL and maxdiff(mu, g["mu0"]) < TOL and maxdiff(logvar, g["logvar0"]) < TOL
             assert max(rep.values()) < 2e-4, rep
         if cfg["clip"] is not None:
@@ -119,13 +125,14 @@ def test_dropin_train_loop_matches_reference(name):
             assert worst < 0.2 * cfg["lr"] * (s + 1)
 
 
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("name", TRAIN)
-def test_fused_trainer_matches_reference(name):
+def test_fused_trainer_matches_reference(name, prec):
     """Fused path: forward -> shm_vae_loss -> backward -> shm_adam_step (clip + Adam in HIP)."""
     from shm_hip.trainer import VAETrainer
     g = load_golden(name)
     cfg = g["cfg"]
-    m = build_module(cfg, split_prefix(g, "p0."), dropout=0.0).train()
+    m = build_module(cfg, split_prefix(g, "p0."), dropout=0.0, precision=prec).train()
     tr = VAETrainer(m, lr=cfg["lr"], weight_decay=cfg["wd"], max_norm=cfg["clip"])
     n = cfg["n_steps"]
     for s in range(n):
@@ -141,11 +148,13 @@ def test_fused_trainer_matches_reference(name):
         if s == 0 or s == n - 1:
             sd = m.state_dict()
             worst = max(maxdiff(sd[k], v) for k, v in split_prefix(g, f"p{s + 1}.").items())
-            print(name, "fused params after step", s + 1, "max abs diff", worst)
+            print(name, prec, "fused params after step", s + 1, "max abs diff", worst)
+            record_parity("fused_trainer", f"{name}/{prec}/step{s + 1}", {"param_max_abs": worst})
             assert worst < 0.2 * cfg["lr"] * (s + 1)
 
 
-def test_train_mode_dropout_matches_oracle_with_same_masks():
+@pytest.mark.parametrize("prec", PRECS)
+def test_train_mode_dropout_matches_oracle_with_same_masks(prec):
     """Inter-layer dropout (nn.LSTM dropout=0.3, train mode): the kernels' counter RNG is rebuilt on the host
     (shm_dropout_keep_mask) and fed to the oracle, which then has to agree on losses and gradients."""
     import ctypes as C
@@ -155,16 +164,18 @@ def test_train_mode_dropout_matches_oracle_with_same_masks():
     g = load_golden("vae_train_mini")
     cfg = g["cfg"]
     p0 = split_prefix(g, "p0.")
-    m = build_module(cfg, p0, dropout=0.3).train()
+    m = build_module(cfg, p0, dropout=0.3, precision=prec).train()
     tr = VAETrainer(m, lr=1e-3, weight_decay=1e-5, max_norm=2.0)
     x, eps = g["x0"], g["eps0"]
+    # the split path keeps its sequences in the 4-window tile-blocked row order, and the RNG is indexed by position in that layout
+    mask_fn = lib.shm_dropout_keep_mask_tiled if prec == "split" else lib.shm_dropout_keep_mask
     B, T, H = x.shape[0], x.shape[1], cfg["hidden_dim"]
     seed = 0x1234ABCD5678
     stats = tr.step(torch.tensor(x).cuda(), 0.37, eps=torch.tensor(eps).cuda(), drop_seed=seed).cpu().numpy()
     masks = {}
     for stack, key in ((0, "enc"), (1, "dec")):
         buf = np.zeros(B * T * H, dtype=np.uint8)
-        lib.shm_dropout_keep_mask(C.c_uint64(seed), stack, B, T, H, C.c_float(0.3), buf.ctypes.data_as(C.c_void_p))
+        mask_fn(C.c_uint64(seed), stack, B, T, H, C.c_float(0.3), buf.ctypes.data_as(C.c_void_p))
         masks[key] = buf.reshape(B, T, H).astype(np.float64)
         assert 0.6 < masks[key].mean() < 0.8
     o = VAEOracle(p0, 2, True)
@@ -176,8 +187,9 @@ def test_train_mode_dropout_matches_oracle_with_same_masks():
     assert max(rep.values()) < 2e-4, rep
 
 
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("B,T", [(1, 1), (1, 7), (17, 3), (33, 20)])
-def test_ragged_batches_and_tiny_windows_match_oracle(B, T):
+def test_ragged_batches_and_tiny_windows_match_oracle(B, T, prec):
     """Batch sizes that do not fill a 16-window tile (the reference keeps the partial last batch, 03_train_vae.py:232)."""
     from oracle.vae_oracle import VAEOracle
     g = load_golden("vae_fwd_mini")
@@ -188,13 +200,14 @@ def test_ragged_batches_and_tiny_windows_match_oracle(B, T):
     eps = rng.standard_normal((B, cfg["latent_dim"])).astype(np.float32)
     o = VAEOracle(p, 2, True)
     recon, mu, lv, score = o.forward(x, eps)
-    m = build_module(cfg, p).eval()
+    m = build_module(cfg, p, precision=prec).eval()
     with torch.no_grad(), inject_eps([torch.tensor(eps)]):
         r2, m2, l2 = m(torch.tensor(x).cuda())
     assert maxdiff(r2, recon) < TOL and maxdiff(m2, mu) < TOL and maxdiff(l2, lv) < TOL
 
 
-@pytest.mark.parametrize("precision,layer_norm,H", [("fp32", False, 32), ("fp32", True, 64), ("bf16", False, 32), ("bf16", True, 128)])
+@pytest.mark.parametrize("precision,layer_norm,H", [("fp32", False, 32), ("fp32", True, 64), ("split", False, 32), ("split", True, 64), ("split", True, 128),
+                                                     ("bf16", False, 32), ("bf16", True, 128)])
 def test_baseline_config0_shape_train_step(precision, layer_norm, H):
     """BASELINE.json configs[0]: the 1_DOF-style LSTM-VAE on ONE channel, seq_len 128, latent 8 — one fused train step (forward, loss,
     BPTT, clip, Adam) against the fp64 oracle.  fp32 path: loss 1e-4, gradients 2e-4 of each tensor's max; bf16 path: DESIGN.md §2 bars."""
@@ -214,7 +227,7 @@ def test_baseline_config0_shape_train_step(precision, layer_norm, H):
     o.forward(x.numpy(), eps.numpy())
     losses, grads = o.loss_and_grads(0.25)
     got = dict(zip([k for k, _, _ in tr.engine.layout], tr.engine.split(tr.grads)))
-    if precision == "fp32":
+    if precision != "bf16":
         assert abs(stats[0] - losses["loss"]) < 1e-4 * max(1.0, losses["loss"])
         rep = _grad_report(got, grads)
         assert max(rep.values()) < 2e-4, rep
@@ -231,11 +244,12 @@ def test_cpu_tensor_is_refused():
         m(torch.zeros(2, 5, 12))
 
 
-def test_full_size_properties():
+@pytest.mark.parametrize("prec", PRECS)
+def test_full_size_properties(prec):
     """North-star size (B=512, T=256, D=4): determinism, batch-split invariance, score definition."""
     from Scripts.Models.temporal_vae import TemporalVAE
     torch.manual_seed(42)
-    m = TemporalVAE(4, 16, 128, 2, 0.3).cuda().eval()
+    m = TemporalVAE(4, 16, 128, 2, 0.3, precision=prec).cuda().eval()
     gen = torch.Generator().manual_seed(1)
     x = torch.randn(512, 256, 4, generator=gen).cuda()
     eps = torch.randn(512, 16, generator=gen)
