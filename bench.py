@@ -65,23 +65,30 @@ def kernel_alg_flops(name, B, path="fp32"):
     return 0
 
 
-PMC_SUMMARY = ROOT / "profiles" / "r01_bf16_pmc_traffic.json"
+PMC_SUMMARIES = {"bf16": ROOT / "profiles" / "r02_bf16_pmc_traffic.json", "split": ROOT / "profiles" / "r02_split_pmc_traffic.json"}
+
+# substrings of the demangled kernel names in the PMC summaries, per profile label
+PMC_KERNELS = {
+    "bf16": {"lstm_fwd": {"enc": "lstm_fwd_pair_bf16_kernel<128, true", "dec": "lstm_fwd_pair_bf16_kernel<128, false",
+                          "enc0": "lstm_fwd_bf16_kernel<128, 1, true", "dec0": "lstm_fwd_bf16_kernel<128, 4, false, false, true",
+                          "enc1": "lstm_fwd_bf16_kernel<128, 4, false, true, false", "dec1": "lstm_fwd_bf16_kernel<128, 4, false, true, false"},
+             "lstm_bwd": {"enc": "lstm_bwd_pair_bf16_kernel<128, 0", "dec": "lstm_bwd_pair_bf16_kernel<128, 2",
+                          "enc0": "lstm_bwd_bf16_kernel<128, 1>", "dec0": "lstm_bwd_bf16_kernel<128, 1>",
+                          "enc1": "lstm_bwd_bf16_kernel<128, 0>", "dec1": "lstm_bwd_bf16_kernel<128, 2>"}},
+    "split": {"lstm_fwd": {"enc0": "lstm_fwd_sp_kernel<128, 2, true>", "enc1": "lstm_fwd_sp_kernel<128, 0, true>",
+                           "dec0": "lstm_fwd_sp_kernel<128, 1, true>", "dec1": "lstm_fwd_sp_kernel<128, 0, true>"},
+              "lstm_bwd": {"enc0": "lstm_bwd_sp_kernel<128, 1>", "dec0": "lstm_bwd_sp_kernel<128, 1>",
+                           "enc1": "lstm_bwd_sp_kernel<128, 0>", "dec1": "lstm_bwd_sp_kernel<128, 2>"}},
+}
 
 
-def pmc_traffic(label, precision):
-    """HBM bytes per launch of the profiled kernel from the committed rocprofv3 --pmc summary (same command, bf16)."""
-    if precision != "bf16" or not PMC_SUMMARY.exists():
-        return None
+def pmc_traffic(label, precision, meta):
+    """HBM bytes per launch of the profiled kernel from a rocprofv3 --pmc summary (profiles/summarize_pmc.py)."""
     kind, _, inst = label.partition(".")
-    want = {"lstm_fwd": {"enc": "lstm_fwd_pair_bf16_kernel<128, true", "dec": "lstm_fwd_pair_bf16_kernel<128, false",
-                         "enc0": "lstm_fwd_bf16_kernel<128, 1, true", "dec0": "lstm_fwd_bf16_kernel<128, 4, false, false, true",
-                         "enc1": "lstm_fwd_bf16_kernel<128, 4, false, true, false", "dec1": "lstm_fwd_bf16_kernel<128, 4, false, true, false"},
-            "lstm_bwd": {"enc": "lstm_bwd_pair_bf16_kernel<128, 0", "dec": "lstm_bwd_pair_bf16_kernel<128, 2",
-                         "enc0": "lstm_bwd_bf16_kernel<128, 1>", "dec0": "lstm_bwd_bf16_kernel<128, 1>",
-                         "enc1": "lstm_bwd_bf16_kernel<128, 0>", "dec1": "lstm_bwd_bf16_kernel<128, 2>"}}.get(kind, {}).get(inst)
+    want = PMC_KERNELS.get(precision, {}).get(kind, {}).get(inst)
     if not want:
         return None
-    for name, v in json.loads(PMC_SUMMARY.read_text())["kernels"].items():
+    for name, v in meta["kernels"].items():
         if want in name:
             return v["hbm_bytes"]
     return None
@@ -134,11 +141,49 @@ def cpu_baseline(sample_windows=128, max_steps=3, budget_s=25.0):
                       f"{cores} threads; same step semantics as the GPU leg"}
 
 
+def cnn_alg_flops(name, B):
+    """Algorithmic FLOPs of one launch group of the CNN step (contractions only) at 2 x T x D windows: SURVEY.md section 8d, CNN row."""
+    H0, W0, H1, W1 = T, D, T // 2, D // 2
+    F = 32 * (T // 4) * (D // 4)
+    conv1, conv2, fc1, fc2 = B * H0 * W0 * 16 * 2 * 9 * 2, B * H1 * W1 * 32 * 16 * 9 * 2, B * F * 128 * 2, B * 128 * 2 * 2
+    return {"cnn.conv1_fwd": conv1, "cnn.conv2_fwd": conv2, "cnn.fc1_fwd": fc1, "cnn.fc2_fwd": fc2, "cnn.conv1_dw": conv1, "cnn.conv2_dw": conv2,
+            "cnn.conv2_dx": conv2, "cnn.fc1_dw": fc1, "cnn.fc1_dx": fc1, "cnn.fc2_dw": fc2, "cnn.fc2_dx": fc2,
+            "cnn.bwd_fused2": 2 * conv2, "cnn.bwd_fused1": conv1}.get(name, 0)
+
+
+def cnn_cpu_baseline(budget_s=15.0, max_steps=40):
+    """The reference CNN step on this box's host cores (oracle/torch_cpu_cnn.py: ATen conv2d / batch_norm / max_pool2d / linear / Adam)."""
+    import torch
+    from oracle.torch_cpu_cnn import TorchCpuCNN
+    from Scripts.Models.cnn_model import CNN
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    torch.manual_seed(42)
+    ref = CNN(2, 2, 0.5, seq_len=T, num_features=D)
+    m = TorchCpuCNN({k: v.detach() for k, v in ref.state_dict().items()}, dropout=0.5)
+    opt = m.make_optimizer(1e-4, 5e-5)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B_PER_GPU, 2, T, D, generator=g)
+    y = torch.randint(0, 2, (B_PER_GPU,), generator=g)
+    m.train_step(opt, x, y)                                  # warm-up
+    t0 = time.perf_counter()
+    steps = 0
+    while steps < max_steps and (steps == 0 or time.perf_counter() - t0 < budget_s):
+        m.train_step(opt, x, y)
+        steps += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(B_PER_GPU * steps / dt, 2), "unit": "windows/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} train steps of {B_PER_GPU} windows (2 x {T} x {D}) after 1 warm-up, torch {torch.__version__} CPU fp32, {cores} threads; "
+                      f"same step semantics as the GPU leg (05_train_cnn.py:270-276)"}
+
+
 def cnn_workload(args):
-    """Secondary line: train step of the 4DOF fault classifier (window + squared-residual channels, 2 x 256 x 4) at 512 windows per
-    step, fp32 (every product on the exact-fp32 MFMA), plus the eval forward.  One GPU."""
+    """Secondary line (BASELINE.json configs[2]): train step of the 4DOF fault classifier (window + squared-residual channels, 2 x 256 x 4)
+    at 512 windows per step, fp32 (every product on the exact-fp32 MFMA), plus the eval forward.  One GPU.  Same contract as the
+    headline: roofline of the dominant kernel from HIP events in this run, cpu_baseline on the host cores."""
     import torch
     from Scripts.Models.cnn_model import CNN
+    from shm_hip._capi import lib, check
     from shm_hip.trainer import CNNTrainer
     if args.gpus != 1:
         raise SystemExit("--workload cnn is a single-GPU line")
@@ -159,6 +204,21 @@ def cnn_workload(args):
     run(args.warmup, args.steps)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    roof = None
+    if args.profile_steps > 0:
+        check(lib.shm_profile_begin(), "shm_profile_begin")
+        run(args.warmup + args.steps, max(args.profile_steps, 4))
+        buf = C.create_string_buffer(1 << 16)
+        check(lib.shm_profile_end(buf, len(buf)), "shm_profile_end")
+        prof = json.loads(buf.value.decode())
+        per = {k: v["ms"] / v["calls"] for k, v in prof.items() if k.startswith("cnn.")}
+        log("cnn kernel profile: " + json.dumps({k: round(v, 4) for k, v in sorted(per.items())}))
+        dom = max((k for k in per if cnn_alg_flops(k, B_PER_GPU) > 0), key=lambda k: per[k])
+        fl = cnn_alg_flops(dom, B_PER_GPU)
+        ach = fl / (per[dom] * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": PEAK_TFLOPS["f32"], "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS["f32"], 5),
+                "traffic": None, "traffic_note": "no PMC pass committed for the CNN line", "avg_launch_ms": round(per[dom], 4), "alg_flops_per_launch": fl,
+                "launch_groups_per_step": len(per), "kernels_ms": {k: round(v, 4) for k, v in sorted(per.items())}}
     m.eval()
     with torch.no_grad():
         for _ in range(3):
@@ -169,68 +229,58 @@ def cnn_workload(args):
             m(x[(i % 16) * B_PER_GPU:(i % 16 + 1) * B_PER_GPU])
         torch.cuda.synchronize()
         de = time.perf_counter() - t1
-    print(json.dumps({"metric": "windows/sec CNN train (4DOF classifier, 2x256x4 windows, bs512)", "value": round(B_PER_GPU * args.steps / dt, 2),
-                      "unit": "windows/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
-                      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                      "config": {"workload": "4DOF CNN train step: conv3x3(2->16)+BN+ReLU+pool, conv3x3(16->32)+BN+ReLU+pool, fc 2048->128 (+dropout 0.5), "
-                                             "fc 128->2, cross-entropy, Adam(1e-4, wd 5e-5); 512 windows of 2 x 256 x 4 per step", "global_batch": B_PER_GPU},
-                      "eval_forward": {"value": round(B_PER_GPU * args.steps / de, 2), "unit": "windows/s", "ms_per_batch": round(1e3 * de / args.steps, 4)}}))
+    step_flops = 3 * sum(cnn_alg_flops(k, 1) for k in ("cnn.conv1_fwd", "cnn.conv2_fwd", "cnn.fc1_fwd", "cnn.fc2_fwd"))
+    value = B_PER_GPU * args.steps / dt
+    out = {"metric": "windows/sec CNN train (4DOF classifier, 2x256x4 windows, bs512)", "value": round(value, 2),
+           "unit": "windows/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "4DOF CNN train step: conv3x3(2->16)+BN+ReLU+pool, conv3x3(16->32)+BN+ReLU+pool, fc 2048->128 (+dropout 0.5), "
+                                  "fc 128->2, cross-entropy, Adam(1e-4, wd 5e-5); 512 windows of 2 x 256 x 4 per step", "global_batch": B_PER_GPU},
+           "alg_flops_per_window_step": step_flops, "whole_step_mfma_frac": round(value * step_flops / (PEAK_TFLOPS["f32"] * 1e12), 5),
+           "roofline": roof,
+           "eval_forward": {"value": round(B_PER_GPU * args.steps / de, 2), "unit": "windows/s", "ms_per_batch": round(1e3 * de / args.steps, 4)}}
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cnn_cpu_baseline()
+    print(json.dumps(out))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-steps", type=int, default=2)
-    ap.add_argument("--precision", choices=["bf16", "fp32", "split"], default="bf16",
-                    help="bf16 (default): bf16 MFMA operands, fp32 accumulate/state/master weights — BASELINE.json configs[1]; "
-                         "fp32: exact-f32 MFMA parity path (1e-4 vs the reference)")
-    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the short fp32 parity-path measurement (N=1 only)")
-    ap.add_argument("--workload", choices=["vae", "cnn"], default="vae",
-                    help="vae (default): the headline LSTM-VAE train step (BASELINE.json metric); cnn: the 4DOF classifier's train step "
-                         "(BASELINE.json configs[2], secondary line, N = 1 only)")
-    args = ap.parse_args()
-    if args.workload == "cnn":
-        return cnn_workload(args)
+def kernel_src_hashes():
+    """sha256 of the kernel sources a PMC summary was collected on / the sources of this tree (profiles/summarize_pmc.py stores the former)."""
+    import hashlib
+    d = ROOT / "hybrid-vae-cnn-for-shm_amd" / "csrc"
+    return {f.name: hashlib.sha256(f.read_bytes()).hexdigest()[:16] for f in sorted(d.glob("*.h*"))}
 
+
+def pmc_traffic_checked(label, precision):
+    """(bytes per launch or None, reason).  The committed PMC summary is only quoted while the kernel sources it was collected on are the
+    sources of this tree: the summary carries their hashes; a mismatch (or a summary without hashes) yields None instead of a stale figure."""
+    summary = PMC_SUMMARIES.get(precision)
+    if summary is None or not summary.exists():
+        return None, "no PMC summary committed for this precision"
+    meta = json.loads(summary.read_text())
+    have = meta.get("kernel_src_sha256")
+    if not have:
+        return None, f"{summary.name} carries no source hashes (collected before they were recorded): not quoted"
+    now = kernel_src_hashes()
+    changed = sorted(k for k in set(have) | set(now) if have.get(k) != now.get(k))
+    if changed:
+        return None, f"{summary.name} is stale: {', '.join(changed)} changed since it was collected"
+    v = pmc_traffic(label, precision, meta)
+    return v, (None if v is not None else "kernel not in the summary")
+
+
+def measure(precision, data, dev, world, rank, steps, warmup, profile_steps, dist):
+    """One leg: `warmup` untimed + `steps` timed train steps of the bench workload on `precision`, barrier + synchronize on both sides,
+    then (outside the timed region) `profile_steps` steps with per-kernel HIP events for the roofline object."""
     import torch
-    import torch.distributed as dist
     from Scripts.Models.temporal_vae import TemporalVAE
     from shm_hip._capi import lib, check
     from shm_hip.trainer import VAETrainer
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 through torch.distributed.run")
-    # Rehearsal knobs for a ONE-GPU box (never set by the driver): SHM_BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0 and
-    # SHM_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device), so the N > 1 control flow can be exercised.
-    if os.environ.get("SHM_BENCH_SINGLE_DEVICE") == "1":
-        local_rank = 0
-    backend = os.environ.get("SHM_BENCH_BACKEND", "nccl")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-
     torch.manual_seed(42)
-    model = TemporalVAE(D, Z, H, L, 0.3, precision=args.precision).to(dev).train()
-    dt_key = {"bf16": "bf16", "fp32": "f32", "split": "bf16x2"}[args.precision]
+    model = TemporalVAE(D, Z, H, L, 0.3, precision=precision).to(dev).train()
+    dt_key = DTYPE_KEY[precision]
     trainer = VAETrainer(model, lr=1e-3, weight_decay=1e-5, max_norm=2.0, seed=42)
-
-    # S1 synthetic windows, resident on the device (SURVEY.md §8d): no H2D inside the timed region
-    n_resident = 16 * B_PER_GPU
-    gen = torch.Generator().manual_seed(42 + rank)
-    data = torch.randn(n_resident, T, D, generator=gen).to(dev)
-    n_batches = n_resident // B_PER_GPU
-
+    n_batches = data.size(0) // B_PER_GPU
     marks = []                         # one event per timed step (enqueued, never waited on inside the loop): per-step spread afterwards
 
     def run(k0, k, mark=False):
@@ -246,88 +296,149 @@ def main():
         if world > 1:
             dist.barrier()
 
-    log(f"rank {rank}/{world}: data resident, starting {args.warmup} warm-up steps")
+    log(f"[{precision}] rank {rank}/{world}: {warmup} warm-up steps")
     tw = time.perf_counter()
-    run(0, args.warmup)
+    run(0, warmup)
     torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
-    log(f"warm-up done in {time.perf_counter() - tw:.2f}s; timing {args.steps} steps")
+    log(f"[{precision}] warm-up done in {time.perf_counter() - tw:.2f}s; timing {steps} steps")
     ev0 = torch.cuda.Event(enable_timing=True)
     ev0.record()
     t0 = time.perf_counter()
-    run(args.warmup, args.steps, mark=True)
+    run(warmup, steps, mark=True)
     torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     per_step = sorted(a.elapsed_time(b2) for a, b2 in zip([ev0] + marks[:-1], marks))      # GPU time between consecutive step ends, ms
     pct = lambda f: round(per_step[min(len(per_step) - 1, int(f * len(per_step)))], 4)
     step_ms = {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9)} if per_step else None
-    log(f"timed region: {dt:.3f}s for {args.steps} steps")
+    log(f"[{precision}] timed region: {dt:.3f}s for {steps} steps")
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     stats = trainer.stats.cpu().tolist()
-    trainer.engine.check_status()          # raises if an in-launch layer hand-off ever timed out (results would be invalid)
+    trainer.check()                        # sticky hand-off status word: raises if ANY step of this leg ran with a timed-out hand-off
+    trainer.engine.check_status()
 
     # per-kernel durations with HIP events on the launch stream (outside the timed region)
     # EVERY rank runs these steps (a step contains the gradient all-reduce, a collective); only rank 0 records events
     roof = None
-    if args.profile_steps > 0 and rank != 0:
-        run(args.warmup + args.steps, args.profile_steps)
+    if profile_steps > 0 and rank != 0:
+        run(warmup + steps, profile_steps)
         torch.cuda.synchronize()
-    if rank == 0 and args.profile_steps > 0:
+    if rank == 0 and profile_steps > 0:
         check(lib.shm_profile_begin(), "shm_profile_begin")
-        run(args.warmup + args.steps, args.profile_steps)
+        run(warmup + steps, profile_steps)
         buf = C.create_string_buffer(1 << 16)
         check(lib.shm_profile_end(buf, len(buf)), "shm_profile_end")
         prof = json.loads(buf.value.decode())
-        log("kernel profile: " + json.dumps(prof))
+        log(f"[{precision}] kernel profile: " + json.dumps(prof))
         per = {k: v["ms"] / v["calls"] for k, v in prof.items()}
-        dom = max((k for k in per if kernel_alg_flops(k, B_PER_GPU, args.precision) > 0), key=lambda k: per[k])
-        fl = kernel_alg_flops(dom, B_PER_GPU, args.precision)
+        dom = max((k for k in per if kernel_alg_flops(k, B_PER_GPU, precision) > 0), key=lambda k: per[k])
+        fl = kernel_alg_flops(dom, B_PER_GPU, precision)
         achieved = fl / (per[dom] * 1e-3) / 1e12
         peak = PEAK_TFLOPS[dt_key]
+        traffic, why = pmc_traffic_checked(dom, precision)
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 5), "traffic": pmc_traffic(dom, args.precision), "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
+                "frac": round(achieved / peak, 5), "traffic": traffic, "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
                 "avg_launch_ms": round(per[dom], 4),
-                "hbm_achieved_GBps": (round(pmc_traffic(dom, args.precision) / (per[dom] * 1e-3) / 1e9, 1) if pmc_traffic(dom, args.precision) else None),
+                "hbm_achieved_GBps": (round(traffic / (per[dom] * 1e-3) / 1e9, 1) if traffic else None),
                 "alg_flops_per_launch": fl, "kernels_ms": {k: round(v, 4) for k, v in sorted(per.items())}}
+        if why:
+            roof["traffic_note"] = why
     barrier()
+    value = world * B_PER_GPU * steps / dt
+    step_flops = 3 * alg_flops_forward_per_window()
+    out = {"value": round(value, 2), "unit": "windows/s", "ms_per_step": round(1e3 * dt / steps, 4), "steps": steps, "warmup": warmup, "dtype": dt_key,
+           "whole_step_mfma_frac": round(value * step_flops / (world * PEAK_TFLOPS[dt_key] * 1e12), 5), "step_ms": step_ms,
+           "final_stats": {"loss": stats[0], "recon": stats[1], "kl": stats[2], "grad_norm": stats[3]}, "roofline": roof}
+    del trainer, model
+    torch.cuda.empty_cache()
+    return out
 
+
+DTYPE_KEY = {"bf16": "bf16", "fp32": "f32", "split": "bf16x2"}
+PRECISION_NOTE = {
+    "bf16": "bf16 MFMA operands, fp32 accumulate / cell state / master weights (BASELINE.json configs[1]); parity at its own documented bars",
+    "split": "every MFMA operand a bf16 pair hi + lo (16 significant bits), products hi*hi + hi*lo + lo*hi in fp32, fp32 state: holds the "
+             "reference's fp32 results to ~1e-6 (north_star's 1e-4 bar) — the parity-grade fast path",
+    "fp32": "exact-fp32 MFMA (v_mfma_f32_16x16x4_f32), bitwise an fmaf chain: the arithmetic reference of the build, slow",
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200, help="timed steps (SURVEY.md section 8d protocol: 20 warm-up + 200 timed)")
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=2)
+    ap.add_argument("--precision", choices=["bf16", "fp32", "split"], default="bf16",
+                    help="headline leg.  bf16 (default): BASELINE.json configs[1]; split: bf16 hi+lo operand pairs, the 1e-4 parity-grade fast "
+                         "path; fp32: exact-f32 MFMA")
+    ap.add_argument("--no-parity-leg", action="store_true", help="skip the parity-grade (split) leg that follows a bf16 headline at N = 1")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the short exact-fp32 measurement (N = 1 only)")
+    ap.add_argument("--workload", choices=["vae", "cnn"], default="vae",
+                    help="vae (default): the headline LSTM-VAE train step (BASELINE.json metric); cnn: the 4DOF classifier's train step "
+                         "(BASELINE.json configs[2], secondary line, N = 1 only)")
+    args = ap.parse_args()
+    if args.workload == "cnn":
+        return cnn_workload(args)
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 through torch.distributed.run")
+    # Rehearsal knobs for a ONE-GPU box (never set by the driver): SHM_BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0 and
+    # SHM_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device), so the N > 1 control flow can be exercised
+    # (tests/test_gpu_multirank.py does).
+    if os.environ.get("SHM_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("SHM_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+
+    # S1 synthetic windows, resident on the device (SURVEY.md §8d): no H2D inside the timed region
+    n_resident = 16 * B_PER_GPU
+    gen = torch.Generator().manual_seed(42 + rank)
+    data = torch.randn(n_resident, T, D, generator=gen).to(dev)
+
+    head = measure(args.precision, data, dev, world, rank, args.steps, args.warmup, args.profile_steps, dist)
     if rank == 0:
-        total_windows = world * B_PER_GPU * args.steps
-        value = total_windows / dt
-        step_flops = 3 * alg_flops_forward_per_window()
         out = {
             "metric": "windows/sec LSTM-VAE train (4DOF, seq256x4ch, bs512) at 1/2/4/8 GPU",
-            "value": round(value, 2), "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": dt_key, "data": "synthetic",
+            "value": head["value"], "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": head["dtype"], "data": "synthetic",
             "config": {"workload": "4DOF LSTM-VAE train step: TemporalVAE(D=4,Z=16,H=128,L=2,dropout=0.3), T=256, "
                                    "batch 512 windows/GPU, fwd+loss+BPTT+clip(2.0)+Adam(1e-3,wd 1e-5), kl_w=0.5",
-                       "global_batch": world * B_PER_GPU, "seq_len": T, "parallelism": f"dp{world}"},
-            "alg_flops_per_window_step": step_flops,
-            "whole_step_mfma_frac": round(value * step_flops / (world * PEAK_TFLOPS[dt_key] * 1e12), 5),
-            "step_ms": step_ms,
-            "final_stats": {"loss": stats[0], "recon": stats[1], "kl": stats[2], "grad_norm": stats[3]},
-            "roofline": roof,
+                       "global_batch": world * B_PER_GPU, "seq_len": T, "parallelism": f"dp{world}",
+                       "precision": args.precision, "precision_note": PRECISION_NOTE[args.precision]},
+            "alg_flops_per_window_step": 3 * alg_flops_forward_per_window(),
+            "whole_step_mfma_frac": head["whole_step_mfma_frac"], "step_ms": head["step_ms"], "final_stats": head["final_stats"],
+            "roofline": head["roofline"],
         }
-        if world == 1 and args.precision == "bf16" and not args.no_fp32_leg:
-            # the fp32 parity path (recon/mu/logvar within 1e-4 of the reference) on the same workload, same run
-            del trainer
-            torch.manual_seed(42)
-            m32 = TemporalVAE(D, Z, H, L, 0.3, precision="fp32").to(dev).train()
-            tr32 = VAETrainer(m32, lr=1e-3, weight_decay=1e-5, max_norm=2.0, seed=42)
-            for i in range(2):
-                tr32.step(data[i * B_PER_GPU:(i + 1) * B_PER_GPU], KL_W)
-            torch.cuda.synchronize()
-            t32 = time.perf_counter()
-            n32 = 8
-            for i in range(n32):
-                tr32.step(data[(i % n_batches) * B_PER_GPU:((i % n_batches) + 1) * B_PER_GPU], KL_W)
-            torch.cuda.synchronize()
-            d32 = time.perf_counter() - t32
-            out["fp32_parity_path"] = {"value": round(B_PER_GPU * n32 / d32, 2), "unit": "windows/s", "ms_per_step": round(1e3 * d32 / n32, 4),
-                                       "steps": n32, "dtype": "f32", "whole_step_mfma_frac": round(B_PER_GPU * n32 / d32 * step_flops / (PEAK_TFLOPS["f32"] * 1e12), 5)}
+    if world == 1 and args.precision == "bf16" and not args.no_parity_leg:
+        # the parity-grade fast path (recon / mu / logvar within 1e-4 of the reference, measured ~1e-6) on the same workload, same run,
+        # with its own roofline object; at least 50 timed steps
+        k = max(50, min(args.steps, 100))
+        leg = measure("split", data, dev, 1, 0, k, max(5, min(args.warmup, 10)), args.profile_steps, dist)
+        leg["precision"] = "split"; leg["precision_note"] = PRECISION_NOTE["split"]
+        out["parity_path"] = leg
+    if world == 1 and args.precision != "fp32" and not args.no_fp32_leg:
+        leg = measure("fp32", data, dev, 1, 0, 6, 2, 0, dist)
+        leg["precision"] = "fp32"; leg["precision_note"] = PRECISION_NOTE["fp32"]
+        out["fp32_exact_path"] = leg
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -65,6 +65,8 @@ class TemporalVAE(nn.Module):
 
     # ------------------------------------------------------------------ reference API
     def reparameterize(self, mu: torch.Tensor, logvar: torch.Tensor) -> torch.Tensor:
+        """temporal_vae.py:60-63, for callers that use it on its own (forward() fuses it into the head kernel).  Three elementwise
+        torch ops on [B, Z]: plumbing-sized, and the only arithmetic in this file."""
         std = torch.exp(0.5 * logvar)
         eps = torch.randn_like(std)
         return mu + eps * std
@@ -89,10 +91,24 @@ class TemporalVAE(nn.Module):
         recon, mu, logvar, _, _, _ = eng.forward(x, eps, training_plan=False, train_mode=train_mode, drop_seed=drop_seed)
         return recon, mu, logvar
 
-    # encode/decode of the reference are folded into the fused forward; kept for callers that use them directly
+    # encode / decode of the reference as separate entry points (inference; gradients flow through forward() only)
+    @torch.no_grad()
     def encode(self, x: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
-        _, mu, logvar = self.forward(x)
-        return mu, logvar
+        """temporal_vae.py:51-58: (mu, logvar); the decoder does not run (shm_vae_encode)."""
+        eng = self._engine
+        eng.bind_parameters(dict(self.named_parameters()))
+        train_mode = self.training and self.dropout > 0.0
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if train_mode else 0
+        return eng.encode(x, train_mode=train_mode, drop_seed=seed)
+
+    @torch.no_grad()
+    def decode(self, z: torch.Tensor, seq_len: int) -> torch.Tensor:
+        """temporal_vae.py:65-70: z [B, Z] -> x_hat [B, seq_len, D]; the encoder does not run (shm_vae_decode)."""
+        eng = self._engine
+        eng.bind_parameters(dict(self.named_parameters()))
+        train_mode = self.training and self.dropout > 0.0
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if train_mode else 0
+        return eng.decode(z, seq_len, train_mode=train_mode, drop_seed=seed)
 
     @torch.no_grad()
     def score(self, x: torch.Tensor) -> torch.Tensor:

@@ -27,19 +27,16 @@ void set_error(const char* fmt, ...) {
 struct ProfEntry { char name[32]; hipEvent_t e0, e1; };
 static thread_local bool g_prof_on = false;
 static thread_local std::vector<ProfEntry>* g_prof = nullptr;
-struct KernelTimer {
-    hipStream_t s; int idx = -1;
-    KernelTimer(const char* name, hipStream_t stream) : s(stream) {
-        if (!g_prof_on || !g_prof) return;
-        ProfEntry e;
-        snprintf(e.name, sizeof(e.name), "%s", name);
-        if (hipEventCreate(&e.e0) != hipSuccess || hipEventCreate(&e.e1) != hipSuccess) return;
-        (void)hipEventRecord(e.e0, s);
-        g_prof->push_back(e);
-        idx = (int)g_prof->size() - 1;
-    }
-    ~KernelTimer() { if (idx >= 0) (void)hipEventRecord((*g_prof)[idx].e1, s); }
-};
+KernelTimer::KernelTimer(const char* name, hipStream_t stream) : s(stream) {
+    if (!g_prof_on || !g_prof) return;
+    ProfEntry e;
+    snprintf(e.name, sizeof(e.name), "%s", name);
+    if (hipEventCreate(&e.e0) != hipSuccess || hipEventCreate(&e.e1) != hipSuccess) return;
+    (void)hipEventRecord(e.e0, s);
+    g_prof->push_back(e);
+    idx = (int)g_prof->size() - 1;
+}
+KernelTimer::~KernelTimer() { if (idx >= 0) (void)hipEventRecord((*g_prof)[idx].e1, s); }
 
 struct LayerInst {
     int In = 0;
@@ -77,6 +74,7 @@ struct shm_vae_plan {
     size_t ws_bytes;
     // call-order state
     bool packed, fwd_saved, loss_done, drop_active;
+    bool err_armed;         // the sticky hand-off error word has been cleared once (first pack_weights on this plan / explicit reset)
     int sync_next;          // which of the two pair-launch sync blocks is all-zero and goes to the next pair launch
     uint64_t drop_seed;
     float* recon_ptr;       // where the last forward left recon (caller buffer or workspace)
@@ -342,7 +340,10 @@ extern "C" int shm_vae_pack_weights(shm_vae_plan* p, const float* params, void* 
             j.src = src; j.src2 = src2; j.dst = dst; j.kind = kind; j.H = H; j.K = K;
         };
         add(params, nullptr, at<float>(ws, p->params_copy), 3, (int)p->n_params);
-        add(nullptr, nullptr, at<char>(ws, p->misc), 4, (int)(misc_bytes(p->B) / 4));          // sticky error word + zero line + tile counters
+        // zero line + tile counters on every pack; the sticky error word in front of them ONLY the first time (the workspace arrives
+        // uninitialised) — afterwards it survives re-packing, so a hand-off timeout stays visible until shm_vae_plan_reset_status
+        if (!p->err_armed) { add(nullptr, nullptr, at<char>(ws, p->misc), 4, (int)(misc_bytes(p->B) / 4)); p->err_armed = true; }
+        else add(nullptr, nullptr, at<char>(ws, p->misc + 64), 4, (int)((misc_bytes(p->B) - 64) / 4));
         if (p->pair_sync)                                                                      // the block the next pair launch uses
             add(nullptr, nullptr, at<char>(ws, p->pair_sync + (size_t)p->sync_next * lstm_fwd_pair_sync_bytes(p->B)), 4,
                 (int)(lstm_fwd_pair_sync_bytes(p->B) / 4));
@@ -395,12 +396,13 @@ extern "C" int shm_vae_pack_weights(shm_vae_plan* p, const float* params, void* 
     return SHM_OK;
 }
 
-extern "C" int shm_vae_forward(shm_vae_plan* p, const float* x, const float* eps, float* recon, float* mu, float* logvar,
-                               float* score, int32_t train_mode, uint64_t drop_seed, void* ws, void* stream) {
+// what: 0 = TemporalVAE.forward (temporal_vae.py:72-77), 1 = encode only (:51-58), 2 = decode only from z_in (:65-70)
+enum { VAE_FULL = 0, VAE_ENCODE = 1, VAE_DECODE = 2 };
+static int vae_forward_impl(shm_vae_plan* p, const float* x, const float* eps, const HeadNoise& rng, const float* z_in, float* recon, float* mu,
+                            float* logvar, float* score, int32_t train_mode, uint64_t drop_seed, void* ws, void* stream, int what) {
     int rc = check_ws(p, ws);
     if (rc) return rc;
     SHM_REQUIRE(p->packed, SHM_ESTATE, "forward: call shm_vae_pack_weights first");
-    SHM_REQUIRE(x && eps, SHM_EINVAL, "forward: x or eps is NULL");
     hipStream_t s = (hipStream_t)stream;
     const shm_vae_config& c = p->cfg;
     const int B = p->B, T = p->T, D = c.input_dim, H = c.hidden_dim, Z = c.latent_dim, L = c.num_layers;
@@ -408,8 +410,6 @@ extern "C" int shm_vae_forward(shm_vae_plan* p, const float* x, const float* eps
     const float drop = (train_mode && L > 1) ? c.dropout : 0.f;
     p->drop_active = drop > 0.f; p->drop_seed = drop_seed;
     p->fwd_saved = false; p->loss_done = false;
-
-    SHM_HIP_CHECK(hipMemcpyAsync(at<float>(ws, p->eps), eps, sizeof(float) * B * Z, hipMemcpyDeviceToDevice, s));
 
     auto run_stack = [&](LayerInst* st, const float* in0, uint32_t stack, float* h_last) -> int {
         auto fwd_args = [&](int l) {
@@ -511,13 +511,17 @@ extern "C" int shm_vae_forward(shm_vae_plan* p, const float* x, const float* eps
         return SHM_OK;
     };
     const float* prm = at<float>(ws, p->params_copy);
-    if (sp) { if ((rc = run_stack_sp(p->enc, x, 0, at<float>(ws, p->h_last)))) return rc; }
-    else if ((rc = run_stack(p->enc, x, 0, at<float>(ws, p->h_last)))) return rc;
-    {
-        KernelTimer kt("head_fwd", s);
-        if ((rc = launch_head_fwd(B, H, Z, c.layer_norm, at<float>(ws, p->h_last), at<float>(ws, p->eps), head_params(p, prm),
-                                  head_bufs(p, ws), mu, logvar, s))) return rc;
+    if (what != VAE_DECODE) {
+        if (sp) { if ((rc = run_stack_sp(p->enc, x, 0, at<float>(ws, p->h_last)))) return rc; }
+        else if ((rc = run_stack(p->enc, x, 0, at<float>(ws, p->h_last)))) return rc;
     }
+    {
+        // the noise that is used (injected, or drawn here by the counter RNG) is kept in the workspace for the backward
+        KernelTimer kt("head_fwd", s);
+        if ((rc = launch_head_fwd(B, H, Z, c.layer_norm, at<float>(ws, p->h_last), eps, head_params(p, prm),
+                                  head_bufs(p, ws), mu, logvar, s, rng, what == VAE_DECODE ? z_in : nullptr, at<float>(ws, p->eps)))) return rc;
+    }
+    if (what == VAE_ENCODE) return SHM_OK;
     if (sp) { if ((rc = run_stack_sp(p->dec, at<float>(ws, p->h0), 1, nullptr))) return rc; }
     else if ((rc = run_stack(p->dec, at<float>(ws, p->h0), 1, nullptr))) return rc;
     float* rec = recon ? recon : (p->training ? at<float>(ws, p->recon) : nullptr);
@@ -533,8 +537,35 @@ extern "C" int shm_vae_forward(shm_vae_plan* p, const float* x, const float* eps
     }
     if (score) SHM_HIP_CHECK(hipMemcpyAsync(score, at<float>(ws, p->score), sizeof(float) * B, hipMemcpyDeviceToDevice, s));
     p->recon_ptr = rec;
-    p->fwd_saved = save;
+    p->fwd_saved = save && what == VAE_FULL;
     return SHM_OK;
+}
+
+extern "C" int shm_vae_forward(shm_vae_plan* p, const float* x, const float* eps, float* recon, float* mu, float* logvar,
+                               float* score, int32_t train_mode, uint64_t drop_seed, void* ws, void* stream) {
+    SHM_REQUIRE(x && eps, SHM_EINVAL, "forward: x or eps is NULL");
+    return vae_forward_impl(p, x, eps, HeadNoise{0, 0, 0}, nullptr, recon, mu, logvar, score, train_mode, drop_seed, ws, stream, VAE_FULL);
+}
+
+extern "C" int shm_vae_forward_sample(shm_vae_plan* p, const float* x, uint64_t eps_seed, uint64_t eps_offset, float* recon, float* mu,
+                                      float* logvar, float* score, int32_t train_mode, uint64_t drop_seed, void* ws, void* stream) {
+    SHM_REQUIRE(x != nullptr, SHM_EINVAL, "forward_sample: x is NULL");
+    return vae_forward_impl(p, x, nullptr, HeadNoise{1, eps_seed, eps_offset}, nullptr, recon, mu, logvar, score, train_mode, drop_seed, ws, stream, VAE_FULL);
+}
+
+extern "C" int shm_vae_encode(shm_vae_plan* p, const float* x, float* mu, float* logvar, int32_t train_mode, uint64_t drop_seed, void* ws,
+                              void* stream) {
+    SHM_REQUIRE(x && (mu || logvar), SHM_EINVAL, "encode: x or both outputs NULL");
+    return vae_forward_impl(p, x, nullptr, HeadNoise{0, 0, 0}, nullptr, nullptr, mu, logvar, nullptr, train_mode, drop_seed, ws, stream, VAE_ENCODE);
+}
+
+extern "C" int shm_vae_decode(shm_vae_plan* p, const float* z, float* recon, int32_t train_mode, uint64_t drop_seed, void* ws, void* stream) {
+    SHM_REQUIRE(z && recon, SHM_EINVAL, "decode: z or recon is NULL");
+    return vae_forward_impl(p, nullptr, nullptr, HeadNoise{0, 0, 0}, z, recon, nullptr, nullptr, nullptr, train_mode, drop_seed, ws, stream, VAE_DECODE);
+}
+
+extern "C" void shm_eps_normal(uint64_t seed, uint64_t offset, int64_t n, float* out) {
+    for (int64_t i = 0; i < n; ++i) out[i] = eps_normal(seed, offset, (uint32_t)i);
 }
 
 extern "C" int shm_set_pair_launch(int on) {
@@ -546,13 +577,33 @@ extern "C" int shm_set_pair_launch(int on) {
 extern "C" int shm_vae_plan_status(const shm_vae_plan* p, const void* ws, void* stream) {
     int rc = check_ws(p, ws);
     if (rc) return rc;
-    if (!p->pair_sync) return SHM_OK;
+    if (!p->pair_sync || !p->err_armed) return SHM_OK;
     unsigned word = 0;
     SHM_HIP_CHECK(hipMemcpyAsync(&word, reinterpret_cast<const char*>(ws) + p->misc, 4,
                                  hipMemcpyDeviceToHost, (hipStream_t)stream));
     SHM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
-    SHM_REQUIRE(word == 0, SHM_ESTATE, "layer-pipelined launch: the consumer of tile %u gave up waiting for its producer; results since the last "
-                "shm_vae_pack_weights are invalid", word - 1);
+    SHM_REQUIRE(word == 0, SHM_ESTATE, "layer-pipelined launch: the consumer of tile %u gave up waiting for its producer (status word 0x%x); every "
+                "result of this plan since the word was last reset is invalid", (word & 0x7fffffffu) - 1, word);
+    return SHM_OK;
+}
+
+extern "C" int shm_vae_plan_status_word(const shm_vae_plan* p, const void* ws, uint32_t* dst, void* stream) {
+    int rc = check_ws(p, ws);
+    if (rc) return rc;
+    SHM_REQUIRE(dst != nullptr, SHM_EINVAL, "plan_status_word: dst is NULL");
+    if (!p->pair_sync || !p->err_armed) { SHM_HIP_CHECK(hipMemsetAsync(dst, 0, 4, (hipStream_t)stream)); return SHM_OK; }
+    SHM_HIP_CHECK(hipMemcpyAsync(dst, reinterpret_cast<const char*>(ws) + p->misc, 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return SHM_OK;
+}
+
+extern "C" int64_t shm_vae_plan_status_offset(const shm_vae_plan* p) { return (p && p->pair_sync) ? (int64_t)p->misc : -1; }
+
+extern "C" int shm_vae_plan_reset_status(shm_vae_plan* p, void* ws, void* stream) {
+    int rc = check_ws(p, ws);
+    if (rc) return rc;
+    if (!p->pair_sync) return SHM_OK;
+    SHM_HIP_CHECK(hipMemsetAsync(reinterpret_cast<char*>(ws) + p->misc, 0, 64, (hipStream_t)stream));
+    p->err_armed = true;
     return SHM_OK;
 }
 

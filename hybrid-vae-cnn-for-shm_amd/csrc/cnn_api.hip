@@ -144,20 +144,36 @@ extern "C" int shm_cnn_forward(shm_cnn_plan* p, const float* params, float* runn
     float* y1 = at<float>(ws, p->y1); float* p1 = at<float>(ws, p->p1);
     float* y2 = at<float>(ws, p->y2); float* p2 = at<float>(ws, p->p2);
     // block 1
+    { KernelTimer kt("cnn.conv1_fwd", (hipStream_t)stream);
     if ((rc = cnn_conv_fwd(1, B, p->H0, p->W0, x, params + p->c1w, params + p->c1b, y1, train ? at<float>(ws, p->part1) : nullptr, s))) return rc;
+    }
+    { KernelTimer kt("cnn.bn1_fin", (hipStream_t)stream);
     if ((rc = cnn_bn_finalize(C1, B, (long long)B * p->H0 * p->W0, train, at<float>(ws, p->part1), params + p->g1, params + p->b1, running,
                               running + 16, at<float>(ws, p->mean1), at<float>(ws, p->rstd1), at<float>(ws, p->scale1), at<float>(ws, p->shift1), s))) return rc;
+    }
+    { KernelTimer kt("cnn.bn1_pool", (hipStream_t)stream);
     if ((rc = cnn_bn_relu_pool(B, C1, p->H0, p->W0, y1, at<float>(ws, p->scale1), at<float>(ws, p->shift1), p1, at<unsigned char>(ws, p->i1), s))) return rc;
+    }
     // block 2
+    { KernelTimer kt("cnn.conv2_fwd", (hipStream_t)stream);
     if ((rc = cnn_conv_fwd(2, B, p->H1, p->W1, p1, params + p->c2w, params + p->c2b, y2, train ? at<float>(ws, p->part2) : nullptr, s))) return rc;
+    }
+    { KernelTimer kt("cnn.bn2_fin", (hipStream_t)stream);
     if ((rc = cnn_bn_finalize(C2, B, (long long)B * p->H1 * p->W1, train, at<float>(ws, p->part2), params + p->g2, params + p->b2, running + 32,
                               running + 64, at<float>(ws, p->mean2), at<float>(ws, p->rstd2), at<float>(ws, p->scale2), at<float>(ws, p->shift2), s))) return rc;
+    }
+    { KernelTimer kt("cnn.bn2_pool", (hipStream_t)stream);
     if ((rc = cnn_bn_relu_pool(B, C2, p->H1, p->W1, y2, at<float>(ws, p->scale2), at<float>(ws, p->shift2), p2, at<unsigned char>(ws, p->i2), s))) return rc;
+    }
     // dense head (flatten is a no-op on the NCHW pooled tensor)
     const float dp = train ? p->cfg.dropout : 0.f;
+    { KernelTimer kt("cnn.fc1_fwd", (hipStream_t)stream);
     if ((rc = cnn_linear_fwd(B, p->F, FC1, p2, params + p->f1w, params + p->f1b, at<float>(ws, p->z1), at<float>(ws, p->a1), 1, dp, drop_seed, s))) return rc;
+    }
     float* lg = at<float>(ws, p->logits);
+    { KernelTimer kt("cnn.fc2_fwd", (hipStream_t)stream);
     if ((rc = cnn_linear_fwd(B, FC1, NC, at<float>(ws, p->a1), params + p->f2w, params + p->f2b, nullptr, lg, 0, 0.f, 0, s))) return rc;
+    }
     if (logits) SHM_HIP_CHECK(hipMemcpyAsync(logits, lg, sizeof(float) * B * NC, hipMemcpyDeviceToDevice, s));
     p->drop_seed = drop_seed; p->drop_p_used = dp;
     p->fwd_saved = train && p->training;
@@ -169,8 +185,10 @@ extern "C" int shm_cnn_loss(shm_cnn_plan* p, const int64_t* labels, float* loss,
     if (rc) return rc;
     SHM_REQUIRE(p->training && p->fwd_saved, SHM_ESTATE, "cnn loss: needs a train-mode forward on a training plan first");
     SHM_REQUIRE(labels && loss, SHM_EINVAL, "cnn loss: labels or loss is NULL");
+    { KernelTimer kt("cnn.ce_loss", (hipStream_t)stream);
     if ((rc = cnn_ce_loss(p->B, p->cfg.num_classes, at<float>(ws, p->logits), (const long long*)labels, at<float>(ws, p->dlogits), loss,
                           (hipStream_t)stream))) return rc;
+    }
     p->loss_done = true;
     return SHM_OK;
 }
@@ -199,20 +217,36 @@ extern "C" int shm_cnn_backward(shm_cnn_plan* p, const float* params, const floa
         return launch_gemm_tn_f32(g, s, &rjobs);
     };
     // fc2: dW = dl^T a1, db = colsum(dl), da1 = dl W2 with the dropout and ReLU masks of fc1 re-applied -> dz1
+    { KernelTimer kt("cnn.fc2_dw", (hipStream_t)stream);
     if ((rc = gemm(dl, NC, at<float>(ws, p->a1), FC1, grads + p->f2w, p->gemm_partial))) return rc;
+    }
+    { KernelTimer kt("cnn.fc2_db", (hipStream_t)stream);
     if ((rc = launch_colsum(dl, NC, B, NC, grads + p->f2b, nullptr, at<float>(ws, p->colsum_scratch), s, &rjobs))) return rc;
+    }
+    { KernelTimer kt("cnn.fc2_dx", (hipStream_t)stream);
     if ((rc = cnn_linear_bwd_dx(B, FC1, NC, dl, params + p->f2w, at<float>(ws, p->z1), at<float>(ws, p->dz1), p->drop_p_used, p->drop_seed, s))) return rc;
+    }
     // fc1
     const float* dz1 = at<float>(ws, p->dz1);
+    { KernelTimer kt("cnn.fc1_dw", (hipStream_t)stream);
     if ((rc = gemm(dz1, FC1, at<float>(ws, p->p2), F, grads + p->f1w, p->gemm_partial2))) return rc;
+    }
+    { KernelTimer kt("cnn.fc1_db", (hipStream_t)stream);
     if ((rc = launch_colsum(dz1, FC1, B, FC1, grads + p->f1b, nullptr, at<float>(ws, p->colsum_scratch2), s, &rjobs))) return rc;
+    }
+    { KernelTimer kt("cnn.fc1_dx", (hipStream_t)stream);
     if ((rc = cnn_linear_bwd_dx(B, F, FC1, dz1, params + p->f1w, nullptr, at<float>(ws, p->dflat), 0.f, 0, s))) return rc;
+    }
     // block 2
     float* wpart = at<float>(ws, p->wpart);
+    { KernelTimer kt("cnn.bn2_bwd", (hipStream_t)stream);
     if ((rc = cnn_bn_bwd(B, C2, p->H1, p->W1, at<float>(ws, p->dflat), at<unsigned char>(ws, p->i2), at<float>(ws, p->y2), at<float>(ws, p->mean2),
                          at<float>(ws, p->rstd2), params + p->g2, at<float>(ws, p->part2), at<float>(ws, p->k1), at<float>(ws, p->k2),
                          grads + p->g2, grads + p->b2, at<float>(ws, p->dy2), s))) return rc;
+    }
+    { KernelTimer kt("cnn.conv2_dw", (hipStream_t)stream);
     if ((rc = cnn_conv_bwd_weight(2, B, p->H1, p->W1, at<float>(ws, p->dy2), at<float>(ws, p->p1), wpart, s))) return rc;
+    }
     {
         // partial rows are [C2*C1*9 weights | C2 biases]; weights and bias are adjacent in neither buffer, so reduce into a
         // scratch row (the tail of wpart's last row is free: reuse colsum scratch sized >= that) then scatter
@@ -221,18 +255,25 @@ extern "C" int shm_cnn_backward(shm_cnn_plan* p, const float* params, const floa
         if ((rc = reduce_jobs_add(rjobs, wpart, B, nw, n, grads + p->c2w, nullptr))) return rc;
         if ((rc = reduce_jobs_add(rjobs, wpart + nw, B, (size_t)C2, n, grads + p->c2b, nullptr))) return rc;
     }
+    { KernelTimer kt("cnn.conv2_dx", (hipStream_t)stream);
     if ((rc = cnn_conv_bwd_data2(B, p->H1, p->W1, at<float>(ws, p->dy2), params + p->c2w, at<float>(ws, p->dp1), s))) return rc;
+    }
     // block 1
+    { KernelTimer kt("cnn.bn1_bwd", (hipStream_t)stream);
     if ((rc = cnn_bn_bwd(B, C1, p->H0, p->W0, at<float>(ws, p->dp1), at<unsigned char>(ws, p->i1), at<float>(ws, p->y1), at<float>(ws, p->mean1),
                          at<float>(ws, p->rstd1), params + p->g1, at<float>(ws, p->part1), at<float>(ws, p->k1), at<float>(ws, p->k2),
                          grads + p->g1, grads + p->b1, at<float>(ws, p->dy1), s))) return rc;
+    }
     float* wpart1 = at<float>(ws, p->wpart1);
+    { KernelTimer kt("cnn.conv1_dw", (hipStream_t)stream);
     if ((rc = cnn_conv_bwd_weight(1, B, p->H0, p->W0, at<float>(ws, p->dy1), x, wpart1, s))) return rc;
+    }
     {
         const size_t nw = (size_t)C1 * 2 * 9, n = nw + C1;
         if ((rc = reduce_jobs_add(rjobs, wpart1, B, nw, n, grads + p->c1w, nullptr))) return rc;
         if ((rc = reduce_jobs_add(rjobs, wpart1 + nw, B, (size_t)C1, n, grads + p->c1b, nullptr))) return rc;
     }
+    KernelTimer kt("cnn.reduce", s);
     return launch_reduce_batch(rjobs, s);
 }
 

@@ -103,6 +103,27 @@ __host__ __device__ __forceinline__ uint32_t drop_threshold(float p) {   // keep
     return t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
 }
 
+// ---------------------------------------------------------------- reparameterisation noise (counter RNG)
+// eps[i] ~ N(0,1) of stream (seed, offset): Philox4x32-10 on counter (i, 0, offset_lo, offset_hi), key = seed, then Box-Muller on the
+// first two words.  Stateless, so the same element gets the same draw wherever it is computed (head_fwd on the device, shm_eps_normal
+// on the host for tests); replaces torch.randn_like at temporal_vae.py:62 on the fused train step (same distribution, not the same numbers).
+__host__ __device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+__host__ __device__ __forceinline__ float eps_normal(uint64_t seed, uint64_t offset, uint32_t idx) {
+    uint32_t c[4] = {idx, 0u, (uint32_t)offset, (uint32_t)(offset >> 32)};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const float u1 = ((float)(c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);      // (0, 1): 24 random bits, never 0
+    const float u2 = ((float)(c[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+}
+
 __host__ __device__ __forceinline__ int ceil_div(int a, int b) { return (a + b - 1) / b; }
 __host__ __device__ __forceinline__ int round_up(int a, int b) { return ceil_div(a, b) * b; }
 

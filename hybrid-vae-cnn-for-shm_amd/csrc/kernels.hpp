@@ -4,6 +4,14 @@
 
 namespace shm {
 
+// Optional per-launch-group timing with HIP events on the launch stream (shm_profile_begin / shm_profile_end; bench.py's roofline
+// objects).  A no-op unless the calling thread armed it; defined in api.hip.
+struct KernelTimer {
+    hipStream_t s; int idx = -1;
+    KernelTimer(const char* name, hipStream_t stream);
+    ~KernelTimer();
+};
+
 // ---- packed-weight geometry (fp32 MFMA 16x16x4 path) -------------------------------------------------
 // Forward operand  W[4H][K]:  Kpad = round_up(K,16), KQ = Kpad/4 (k-range owned by one lane quarter), S4 = KQ/4.
 //   packed[((ht*S4 + s4)*4 + g)*64 + lane][e] = W[g*H + ht*16 + (lane&15)][(lane>>4)*KQ + 4*s4 + e]   (0 beyond K)
@@ -52,8 +60,12 @@ struct HeadBufs {           // all [B, *] fp32, workspace
 struct HeadParams {
     const float *ln_w, *ln_b, *mu_w, *mu_b, *lv_w, *lv_b, *l2h_w, *l2h_b;
 };
+struct HeadNoise { int on; uint64_t seed, offset; };      // counter RNG for the reparameterisation noise (common.hpp: eps_normal)
+// eps: injected noise [B,Z] or nullptr (then rng, or none: z = mu); z_in: decode-only mode (h0 from a given z); eps_store: where the
+// noise actually used is kept for the backward
 int launch_head_fwd(int B, int H, int Z, int layer_norm, const float* h_last, const float* eps, const HeadParams& p,
-                    const HeadBufs& hb, float* mu_out, float* lv_out, hipStream_t s);
+                    const HeadBufs& hb, float* mu_out, float* lv_out, hipStream_t s, const HeadNoise& rng = HeadNoise{0, 0, 0},
+                    const float* z_in = nullptr, float* eps_store = nullptr);
 // dh0 = dpre_tsum[B,4H] . W_ih_dec0[4H,H]; then back through the head; d_mu/d_lv: upstream grads [B,Z]
 int launch_head_bwd(int B, int H, int Z, int layer_norm, const float* dpre_tsum, const float* W_ih_dec0,
                     const float* eps, const float* d_mu, const float* d_lv, const HeadParams& p, const HeadBufs& hb,

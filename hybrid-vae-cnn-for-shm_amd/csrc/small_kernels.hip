@@ -21,15 +21,34 @@ constexpr int HMAX = 128;   // hidden_dim limit of the head kernels
 constexpr int ZMAX = 32;    // latent_dim limit
 
 // ------------------------------------------------------------------------------------------------ head forward
+// Noise: eps (injected, parity tests and the drop-in module's torch draw) or, with eps == nullptr and rng.on, the counter RNG of
+// common.hpp keyed by (seed, offset); whichever is used is stored in eps_store for the backward.  Neither: z = mu.
+// z_in != nullptr: decode-only (temporal_vae.py:65-67) — the encoder half is skipped and h0 = tanh(fc_latent_to_hidden(z_in)).
 __global__ void __launch_bounds__(256) head_fwd_kernel(int B, int H, int Z, int layer_norm, const float* __restrict__ h_last,
                                                        const float* __restrict__ eps, HeadParams p, HeadBufs hb,
-                                                       float* mu_out, float* lv_out) {
+                                                       float* mu_out, float* lv_out, HeadNoise rng, const float* __restrict__ z_in,
+                                                       float* __restrict__ eps_store) {
     __shared__ float ys[4][HMAX];
     __shared__ float zs[4][ZMAX];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row_raw = blockIdx.x * 4 + w;
     const bool valid = row_raw < B;
     const int row = valid ? row_raw : B - 1;
+    if (z_in) {
+        if (lane < Z) {
+            const float z = z_in[(size_t)row * Z + lane];
+            zs[w][lane] = z;
+            if (valid) hb.z[(size_t)row * Z + lane] = z;
+        }
+        __syncthreads();
+        for (int k = lane; k < H; k += 64) {
+            float acc = p.l2h_b[k];
+            const float* wr = p.l2h_w + (size_t)k * Z;
+            for (int z = 0; z < Z; ++z) acc = fmaf(zs[w][z], wr[z], acc);
+            if (valid) hb.h0[(size_t)row * H + k] = tanhf(acc);
+        }
+        return;
+    }
     const float* h = h_last + (size_t)row * H;
 
     float hv[HMAX / 64], s = 0.f;
@@ -67,9 +86,11 @@ __global__ void __launch_bounds__(256) head_fwd_kernel(int B, int H, int Z, int 
         const float* wl = p.lv_w + (size_t)lane * H;
         for (int k = 0; k < H; ++k) { const float y = ys[w][k]; m = fmaf(y, wm[k], m); l = fmaf(y, wl[k], l); }
         const float sd = expf(0.5f * l);
-        const float z = m + eps[(size_t)row * Z + lane] * sd;
+        const float e = eps ? eps[(size_t)row * Z + lane] : rng.on ? eps_normal(rng.seed, rng.offset, (uint32_t)(row * Z + lane)) : 0.f;
+        const float z = m + e * sd;
         zs[w][lane] = z;
         if (valid) {
+            if (eps_store) eps_store[(size_t)row * Z + lane] = e;
             hb.mu[(size_t)row * Z + lane] = m; hb.lv[(size_t)row * Z + lane] = l; hb.z[(size_t)row * Z + lane] = z;
             if (mu_out) mu_out[(size_t)row * Z + lane] = m;
             if (lv_out) lv_out[(size_t)row * Z + lane] = l;
@@ -262,7 +283,7 @@ __global__ void __launch_bounds__(256) out_fwd_kernel(int T, int D, int H, const
             const size_t o = ((size_t)b * T + t) * D + lane;
             const float r = mine + bias;
             if (recon) recon[o] = r;
-            const float e = x[o] - r;
+            const float e = x ? x[o] - r : 0.f;           // x == nullptr: decode-only, no score
             sq = fmaf(e, e, sq);
         }
     }
@@ -351,7 +372,7 @@ __global__ void __launch_bounds__(64 * OUT_WAVES) out_fwd_mfma_kernel(int B, int
                         const size_t o = ((size_t)b * T + t) * D + j;
                         const float rc = acc[r] + bias;
                         if (recon) recon[o] = rc;
-                        const float e = x[o] - rc;
+                        const float e = x ? x[o] - rc : 0.f;  // x == nullptr: decode-only, no score
                         if (d_recon) d_recon[o] = -e * dsc;
                         sq[r] = fmaf(e, e, sq[r]);
                     }
@@ -736,9 +757,9 @@ __global__ void __launch_bounds__(256) bias_sum_kernel(const float* __restrict__
 }  // namespace
 
 int launch_head_fwd(int B, int H, int Z, int layer_norm, const float* h_last, const float* eps, const HeadParams& p,
-                    const HeadBufs& hb, float* mu_out, float* lv_out, hipStream_t s) {
+                    const HeadBufs& hb, float* mu_out, float* lv_out, hipStream_t s, const HeadNoise& rng, const float* z_in, float* eps_store) {
     SHM_REQUIRE(H <= HMAX && Z <= ZMAX, SHM_EINVAL, "head: H=%d (<=%d) Z=%d (<=%d) unsupported", H, HMAX, Z, ZMAX);
-    SHM_LAUNCH(head_fwd_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, s, B, H, Z, layer_norm, h_last, eps, p, hb, mu_out, lv_out);
+    SHM_LAUNCH(head_fwd_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, s, B, H, Z, layer_norm, h_last, eps, p, hb, mu_out, lv_out, rng, z_in, eps_store);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }

@@ -59,6 +59,10 @@ def _load():
         "shm_vae_plan_workspace_bytes": (C.c_size_t, [vp]),
         "shm_vae_pack_weights": (C.c_int, [vp, f32p, vp, vp]),
         "shm_vae_forward": (C.c_int, [vp, f32p, f32p, f32p, f32p, f32p, f32p, C.c_int32, C.c_uint64, vp, vp]),
+        "shm_vae_forward_sample": (C.c_int, [vp, f32p, C.c_uint64, C.c_uint64, f32p, f32p, f32p, f32p, C.c_int32, C.c_uint64, vp, vp]),
+        "shm_eps_normal": (None, [C.c_uint64, C.c_uint64, C.c_int64, vp]),
+        "shm_vae_encode": (C.c_int, [vp, f32p, f32p, f32p, C.c_int32, C.c_uint64, vp, vp]),
+        "shm_vae_decode": (C.c_int, [vp, f32p, f32p, C.c_int32, C.c_uint64, vp, vp]),
         "shm_olcnn_param_count": (C.c_int64, [C.POINTER(OlCnnConfig)]),
         "shm_olcnn_param_layout": (C.c_int, [C.POINTER(OlCnnConfig), C.POINTER(TensorDesc), C.c_int]),
         "shm_olcnn_workspace_bytes": (C.c_size_t, [C.POINTER(OlCnnConfig), C.c_int32]),
@@ -74,6 +78,9 @@ def _load():
         "shm_cnn_eval_loss": (C.c_int, [vp, vp, C.c_int32, C.c_int32, vp, vp]),
         "shm_vae_eval_loss": (C.c_int, [vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, vp, vp]),
         "shm_vae_plan_status": (C.c_int, [vp, vp, vp]),
+        "shm_vae_plan_status_word": (C.c_int, [vp, vp, vp, vp]),
+        "shm_vae_plan_status_offset": (C.c_int64, [vp]),
+        "shm_vae_plan_reset_status": (C.c_int, [vp, vp, vp]),
         "shm_set_pair_launch": (C.c_int, [C.c_int]),
         "shm_vae_loss": (C.c_int, [vp, f32p, C.c_float, f32p, vp, vp]),
         "shm_vae_backward": (C.c_int, [vp, f32p, f32p, f32p, f32p, f32p, vp, vp]),

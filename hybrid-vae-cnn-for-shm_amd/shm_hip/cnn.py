@@ -68,7 +68,9 @@ class CNNEngine:
         return self.flat
 
     def plan(self, B, training):
-        key = (int(B), bool(training))
+        # shm_cnn_plan_create COPIES the configuration, so the dropout rate is part of the key: a caller that changes fc1[2].p after
+        # the first forward gets a new plan instead of silently keeping the old rate
+        key = (int(B), bool(training), round(float(self.cfg.dropout), 9))
         pl = self._plans.get(key)
         if pl is None:
             if len(self._plans) >= self.MAX_PLANS:

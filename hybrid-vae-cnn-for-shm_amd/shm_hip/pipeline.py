@@ -11,6 +11,13 @@ import torch
 from .cnn import build_cnn_input, predict
 
 
+def _check_status(vae):
+    """Raise if a layer-pipelined launch of the module's engine ever timed out on a hand-off (sticky word, shm_vae_plan_status)."""
+    eng = getattr(vae, "_engine", None)
+    if eng is not None:
+        eng.check_status()
+
+
 @torch.no_grad()
 def score_windows(vae, Z: torch.Tensor, batch: int = 512) -> torch.Tensor:
     """Per-window MSE of 04_vae_thresholding.py:113-124 for Z [N,T,D] (device tensor), in batches."""
@@ -18,6 +25,7 @@ def score_windows(vae, Z: torch.Tensor, batch: int = 512) -> torch.Tensor:
     out = torch.empty(Z.size(0), dtype=torch.float32, device=Z.device)
     for i in range(0, Z.size(0), batch):
         out[i:i + batch] = vae.score(Z[i:i + batch])
+    _check_status(vae)              # one synchronisation per call (the scores go to the host next): a hand-off timeout raises here
     return out
 
 
@@ -47,6 +55,7 @@ def hybrid_predict(vae, cnn, Z: torch.Tensor, threshold: float, batch: int = 512
             cls, p1 = predict(logits)
             y_pred.index_copy_(0, sel, cls + 1)
             p_struct.index_copy_(0, sel, p1)
+        _check_status(vae)
         return mse, y_pred, p_struct
     mse = score_windows(vae, Z, batch)
     idx = torch.nonzero(mse > threshold, as_tuple=False).flatten()
@@ -58,6 +67,7 @@ def hybrid_predict(vae, cnn, Z: torch.Tensor, threshold: float, batch: int = 512
         cls, p1 = predict(logits)
         y_pred.index_copy_(0, sel, cls + 1)
         p_struct.index_copy_(0, sel, p1)
+    _check_status(vae)
     return mse, y_pred, p_struct
 
 

@@ -63,7 +63,11 @@ class VAETrainer:
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self.scratch = torch.zeros(int(lib.shm_adam_scratch_bytes(n)), dtype=torch.uint8, device=dev)
-        self.stats = torch.zeros(4, dtype=torch.float32, device=dev)      # loss, recon, kl, grad_norm
+        # loss, recon, kl, grad_norm, [4] = the plan's sticky hand-off status word (uint32 bits, 0 = healthy): it rides in the buffer
+        # the caller reads back anyway, so a timed-out layer hand-off is seen without any extra synchronisation
+        self.stats = torch.zeros(5, dtype=torch.float32, device=dev)
+        self._err_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._err_event = None
         self.lr, self.wd, self.betas, self.eps, self.max_norm = lr, weight_decay, betas, eps, max_norm
         self.step_count = 0
         self.comm = FlatAllReduce(group)
@@ -80,15 +84,15 @@ class VAETrainer:
         eng = self.engine
         if eng.bind_parameters(self._named) is not self.flat:
             raise RuntimeError("model parameters were re-allocated (e.g. .to()) after the trainer was built")
-        B = x.size(0)
-        if eps is None:
-            eps = torch.randn(B, eng.cfg.latent_dim, dtype=torch.float32, device=x.device, generator=self.gen)
+        self._raise_if_failed(wait=False)      # the status word of an EARLIER step, if its copy has landed: no synchronisation
         self.step_count += 1
         if drop_seed is None:
             drop_seed = (self.seed << 20) + self.step_count
         train_mode = self.model.training and self.model.dropout > 0.0
+        # eps None: the reparameterisation noise is drawn inside the head kernel (counter RNG keyed by this rank's seed and the step) —
+        # no ATen RNG launch on the timed path; an injected eps (parity tests) takes precedence
         _, _, _, _, pl, xc = eng.forward(x, eps, training_plan=True, train_mode=train_mode, drop_seed=drop_seed,
-                                         want_recon=False)
+                                         want_recon=False, eps_stream=(self.seed, self.step_count))
         eng.loss(pl, xc, float(kl_w), self.stats)
         eng.backward(pl, xc, self.grads)
         scale = self.comm(self.grads)
@@ -99,20 +103,56 @@ class VAETrainer:
                                 C.c_float(self.max_norm if self.max_norm is not None else 0.0), C.c_float(scale),
                                 _ptr(self.scratch), C.c_void_p(self.stats.data_ptr() + 12), _stream()), "shm_adam_step")
         eng.mark_dirty()
+        word = self.stats[4:5].view(torch.int32)
+        eng.status_word_into(pl, word)
+        self._err_host.copy_(word, non_blocking=True)
+        self._err_event = torch.cuda.Event()
+        self._err_event.record()
         return self.stats
+
+    def _raise_if_failed(self, wait: bool):
+        ev = self._err_event
+        if ev is None or not (wait or ev.query()):
+            return
+        if wait:
+            ev.synchronize()
+        w = int(self._err_host.item()) & 0xFFFFFFFF
+        if w:
+            raise RuntimeError(f"VAETrainer: a layer-pipelined launch reported a hand-off timeout (status word 0x{w:x}); the parameters, "
+                               "optimiser state and statistics of every step since then are invalid")
+
+    def check(self, host_stats=None):
+        """Raises if any step so far ran with a failed in-launch hand-off.  host_stats: a host copy of the tensor step() returned
+        (then no synchronisation happens here); None: waits for the last step."""
+        if host_stats is not None:
+            import numpy as np
+            w = int(np.asarray(host_stats, dtype=np.float32).view(np.uint32)[4])
+            if w:
+                raise RuntimeError(f"VAETrainer: hand-off timeout in a layer-pipelined launch (status word 0x{w:x}); results are invalid")
+            return
+        self._raise_if_failed(wait=True)
 
     @torch.no_grad()
     def evaluate(self, x: torch.Tensor, kl_w: float, eps: torch.Tensor | None = None):
-        """Validation pass of 03_train_vae.py:284-299: same loss, no state saved, no update. Returns [loss, recon, kl]."""
+        """Validation pass of 03_train_vae.py:284-299: same loss, no state saved, no update.  Returns [loss, recon, kl, status] where
+        status carries the inference plan's sticky hand-off word (uint32 bits, 0 = healthy; VAETrainer.check_eval raises on it)."""
         eng = self.engine
         B = x.size(0)
-        if eps is None:
-            eps = torch.randn(B, eng.cfg.latent_dim, dtype=torch.float32, device=x.device, generator=self.gen)
-        _, mu, lv, score, _, xc = eng.forward(x, eps, training_plan=False, train_mode=False, want_score=True, want_recon=False)
-        out = torch.empty(3, dtype=torch.float32, device=x.device)
+        self._eval_count = getattr(self, "_eval_count", 0) + 1
+        _, mu, lv, score, pl, xc = eng.forward(x, eps, training_plan=False, train_mode=False, want_score=True, want_recon=False,
+                                               eps_stream=(self.seed ^ 0x5EED5EED, self._eval_count))
+        out = torch.empty(4, dtype=torch.float32, device=x.device)
         check(lib.shm_vae_eval_loss(_ptr(mu), _ptr(lv), _ptr(score), B, xc.size(1), xc.size(2), eng.cfg.latent_dim, C.c_float(float(kl_w)),
                                     _ptr(out), _stream()), "shm_vae_eval_loss")
+        eng.status_word_into(pl, out[3:4].view(torch.int32))
         return out
+
+    @staticmethod
+    def check_eval(host_out):
+        import numpy as np
+        w = int(np.asarray(host_out, dtype=np.float32).view(np.uint32)[3])
+        if w:
+            raise RuntimeError(f"VAETrainer.evaluate: hand-off timeout in a layer-pipelined launch (status word 0x{w:x}); results are invalid")
 
 
 class CNNTrainer:
@@ -138,6 +178,14 @@ class CNNTrainer:
         self.seed = seed + 7919 * rank
         if sync_params:
             self.comm.broadcast(self.flat, 0)
+            self.comm.broadcast(self.engine.running, 0)
+
+    def sync_running_stats(self):
+        """Data parallelism: BatchNorm batch statistics stay local to a rank while training (plain DDP semantics), so the running
+        statistics drift apart.  Rank 0's are THE model's (torch DDP broadcasts buffers from rank 0 too): this broadcasts them, and
+        evaluate() / a checkpoint writer call it first so that every rank computes the same validation loss and takes the same
+        early-stopping / best-checkpoint branch (ranks that disagree there would meet unevenly in the next gradient all-reduce)."""
+        self.comm.broadcast(self.engine.running, 0)
 
     def step(self, x: torch.Tensor, y: torch.Tensor, drop_seed: int | None = None):
         """One optimiser step on the local shard; returns the device tensor [loss, grad_norm]."""
@@ -164,6 +212,7 @@ class CNNTrainer:
     @torch.no_grad()
     def evaluate(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
         """Validation CrossEntropy of 05_train_cnn.py:284-292 (eval-mode forward, running statistics); device scalar."""
+        self.sync_running_stats()
         self.model.eval()
         logits = self.model(x)
         out = torch.empty(1, dtype=torch.float32, device=x.device)

@@ -109,16 +109,52 @@ class VAEEngine:
             pl.packed_version = self.version
 
     # -- compute -----------------------------------------------------------------------------------------
-    def forward(self, x, eps, training_plan, train_mode, drop_seed=0, want_score=False, want_recon=True):
+    def _check_x(self, x):
         if x.device.type != "cuda":
             raise RuntimeError("TemporalVAE (MI355X build): input must live on a CUDA (ROCm) device; there is no CPU path")
         if x.dim() != 3 or x.size(2) != self.cfg.input_dim:
             raise RuntimeError(f"expected x of shape [B, T, {self.cfg.input_dim}], got {tuple(x.shape)}")
-        x = x.contiguous().float()
+        return x.contiguous().float()
+
+    def encode(self, x, train_mode=False, drop_seed=0):
+        """mu, logvar of temporal_vae.py:51-58; the decoder does not run."""
+        x = self._check_x(x)
+        B, T, _ = x.shape
+        pl = self.plan(B, T, False)
+        self._pack(pl)
+        mu = torch.empty(B, self.cfg.latent_dim, dtype=torch.float32, device=x.device)
+        lv = torch.empty_like(mu)
+        check(lib.shm_vae_encode(pl.handle, _ptr(x), _ptr(mu), _ptr(lv), int(bool(train_mode)), C.c_uint64(int(drop_seed) & (2 ** 64 - 1)),
+                                 _ptr(pl.ws), _stream()), "shm_vae_encode")
+        self.last_plan = pl
+        return mu, lv
+
+    def decode(self, z, seq_len, train_mode=False, drop_seed=0):
+        """recon [B, seq_len, D] of temporal_vae.py:65-70; the encoder does not run."""
+        if z.device.type != "cuda":
+            raise RuntimeError("TemporalVAE (MI355X build): z must live on a CUDA (ROCm) device; there is no CPU path")
+        if z.dim() != 2 or z.size(1) != self.cfg.latent_dim:
+            raise RuntimeError(f"expected z of shape [B, {self.cfg.latent_dim}], got {tuple(z.shape)}")
+        z = z.contiguous().float()
+        B = z.size(0)
+        pl = self.plan(B, int(seq_len), False)
+        self._pack(pl)
+        recon = torch.empty(B, int(seq_len), self.cfg.input_dim, dtype=torch.float32, device=z.device)
+        check(lib.shm_vae_decode(pl.handle, _ptr(z), _ptr(recon), int(bool(train_mode)), C.c_uint64(int(drop_seed) & (2 ** 64 - 1)),
+                                 _ptr(pl.ws), _stream()), "shm_vae_decode")
+        self.last_plan = pl
+        return recon
+
+    def forward(self, x, eps, training_plan, train_mode, drop_seed=0, want_score=False, want_recon=True, eps_stream=None):
+        """eps: injected noise [B, Z]; or None with eps_stream = (seed, offset): drawn on the device inside the head kernel."""
+        x = self._check_x(x)
         B, T, D = x.shape
-        eps = eps.contiguous().float()
-        if tuple(eps.shape) != (B, self.cfg.latent_dim):
-            raise RuntimeError(f"eps must be [{B}, {self.cfg.latent_dim}], got {tuple(eps.shape)}")
+        if eps is not None:
+            eps = eps.contiguous().float()
+            if tuple(eps.shape) != (B, self.cfg.latent_dim):
+                raise RuntimeError(f"eps must be [{B}, {self.cfg.latent_dim}], got {tuple(eps.shape)}")
+        elif eps_stream is None:
+            raise RuntimeError("forward needs either eps or eps_stream = (seed, offset)")
         pl = self.plan(B, T, training_plan)
         self._pack(pl)
         Z = self.cfg.latent_dim
@@ -126,9 +162,15 @@ class VAEEngine:
         mu = torch.empty(B, Z, dtype=torch.float32, device=x.device)
         lv = torch.empty(B, Z, dtype=torch.float32, device=x.device)
         score = torch.empty(B, dtype=torch.float32, device=x.device) if want_score else None
-        check(lib.shm_vae_forward(pl.handle, _ptr(x), _ptr(eps), _ptr(recon), _ptr(mu), _ptr(lv), _ptr(score),
-                                  int(bool(train_mode)), C.c_uint64(int(drop_seed) & (2 ** 64 - 1)), _ptr(pl.ws), _stream()),
-              "shm_vae_forward")
+        if eps is not None:
+            check(lib.shm_vae_forward(pl.handle, _ptr(x), _ptr(eps), _ptr(recon), _ptr(mu), _ptr(lv), _ptr(score),
+                                      int(bool(train_mode)), C.c_uint64(int(drop_seed) & (2 ** 64 - 1)), _ptr(pl.ws), _stream()),
+                  "shm_vae_forward")
+        else:
+            check(lib.shm_vae_forward_sample(pl.handle, _ptr(x), C.c_uint64(int(eps_stream[0]) & (2 ** 64 - 1)),
+                                             C.c_uint64(int(eps_stream[1]) & (2 ** 64 - 1)), _ptr(recon), _ptr(mu), _ptr(lv), _ptr(score),
+                                             int(bool(train_mode)), C.c_uint64(int(drop_seed) & (2 ** 64 - 1)), _ptr(pl.ws), _stream()),
+                  "shm_vae_forward_sample")
         self.last_plan = pl
         return recon, mu, lv, score, pl, x
 
@@ -140,9 +182,18 @@ class VAEEngine:
                                    _stream()), "shm_vae_backward")
 
     def check_status(self):
-        """Raises if a layer-pipelined launch of any plan reported a hand-off timeout (synchronises the stream)."""
+        """Raises if a layer-pipelined launch of any plan EVER reported a hand-off timeout (synchronises the stream).  The word is
+        sticky: re-packing the weights after an optimiser step does not clear it, only reset_status() does."""
         for pl in self._plans.values():
             check(lib.shm_vae_plan_status(pl.handle, _ptr(pl.ws), _stream()), "shm_vae_plan_status")
+
+    def status_word_into(self, pl, dst_i32):
+        """Copies plan pl's sticky status word (0 = healthy) into the 4-byte device location dst_i32, asynchronously on the stream."""
+        check(lib.shm_vae_plan_status_word(pl.handle, _ptr(pl.ws), C.c_void_p(dst_i32.data_ptr()), _stream()), "shm_vae_plan_status_word")
+
+    def reset_status(self):
+        for pl in self._plans.values():
+            check(lib.shm_vae_plan_reset_status(pl.handle, _ptr(pl.ws), _stream()), "shm_vae_plan_reset_status")
 
     def split(self, flat):
         return [flat[off:off + int(torch.Size(shape).numel())].view(shape) for _, off, shape in self.layout]

@@ -54,6 +54,7 @@ def train_vae(Ztr: np.ndarray, Zva: np.ndarray, out_dir, *, epochs=50, batch_siz
         for i in range(0, xtr.size(0), batch_size):               # drop_last=False: the partial last batch is kept
             xb = xtr.index_select(0, perm[i:i + batch_size])
             s = tr.step(xb, kl_w).cpu().numpy()                    # sample-weighted epoch means, 03:274-282
+            tr.check(s)                                            # sticky hand-off status word rides in s[4]: raises, no extra sync
             sums += s[:3] * xb.size(0); n += xb.size(0)
         tr_avg = sums / max(n, 1)
         vae.eval()
@@ -61,13 +62,17 @@ def train_vae(Ztr: np.ndarray, Zva: np.ndarray, out_dir, *, epochs=50, batch_siz
         for i in range(0, xva.size(0), batch_size):
             xb = xva[i:i + batch_size]
             s = tr.evaluate(xb, kl_w).cpu().numpy()               # validation uses the same kl_w, 03:293
-            sums += s * xb.size(0); n += xb.size(0)
+            tr.check_eval(s)
+            sums += s[:3] * xb.size(0); n += xb.size(0)
         va_avg = sums / max(n, 1)
         for k, v in zip(("train_total", "train_recon", "train_kl"), tr_avg): hist[k].append(float(v))
         for k, v in zip(("val_total", "val_recon", "val_kl"), va_avg): hist[k].append(float(v))
         hist["epoch"].append(epoch); hist["kl_w"].append(float(kl_w))
         log(f"[train] epoch {epoch:03d}/{epochs} | kl_w={kl_w:.6f} | total={tr_avg[0]:.6f} | recon={tr_avg[1]:.6f} | kl={tr_avg[2]:.6f}")
         log(f"[val  ] epoch {epoch:03d}/{epochs} | kl_w={kl_w:.6f} | total={va_avg[0]:.6f} | recon={va_avg[1]:.6f} | kl={va_avg[2]:.6f}")
+        if kl_w > 0.99 and tr_avg[2] < 1e-4:                        # posterior collapse: the decoder ignores z (KL ~ 0 at full weight)
+            log(f"[warn ] epoch {epoch:03d}: KL {tr_avg[2]:.2e} at kl_w {kl_w:.3f} — posterior collapse (reconstruction from the prior only)")
+            hist.setdefault("collapsed_epochs", []).append(epoch)
         if va_avg[0] < best_val:
             best_val, best_epoch = float(va_avg[0]), epoch
             torch.save(vae.state_dict(), out_dir / "temporal_vae_state_dict.pt")
@@ -96,6 +101,7 @@ def train_vae_1dof(Ztr: np.ndarray, out_dir, *, n_epochs=100, batch_size=64, lr=
         sums, nb = np.zeros(3), 0
         for i in range(0, xtr.size(0), batch_size):
             s = tr.step(xtr.index_select(0, perm[i:i + batch_size]), w).cpu().numpy()
+            tr.check(s)
             sums += s[:3]; nb += 1
         avg = sums / max(nb, 1)
         for k, v in zip(("loss_total", "loss_recon", "loss_kl"), avg): hist[k].append(float(v))

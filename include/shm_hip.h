@@ -83,6 +83,23 @@ int  shm_vae_forward(shm_vae_plan* plan, const float* x, const float* eps,
                      float* recon, float* mu, float* logvar, float* score,
                      int32_t train_mode, uint64_t drop_seed, void* workspace, void* stream);
 
+/* The same forward with the reparameterisation noise drawn ON THE DEVICE inside the head kernel (no eps buffer, no separate RNG launch):
+ * eps[b][z] = N(0,1) of the counter RNG (Philox4x32-10 + Box-Muller) keyed by (eps_seed, eps_offset, element b*Z + z) — the production
+ * form of torch.randn_like at temporal_vae.py:62 (same distribution, its own stream; a trainer passes offset = step).  The noise used is
+ * kept in the workspace for shm_vae_backward.  shm_eps_normal is the host replica of that stream (tests rebuild the draw with it). */
+int  shm_vae_forward_sample(shm_vae_plan* plan, const float* x, uint64_t eps_seed, uint64_t eps_offset,
+                            float* recon, float* mu, float* logvar, float* score,
+                            int32_t train_mode, uint64_t drop_seed, void* workspace, void* stream);
+void shm_eps_normal(uint64_t eps_seed, uint64_t eps_offset, int64_t n, float* out);
+
+/* TemporalVAE.encode (temporal_vae.py:51-58): x[B,T,D] -> mu, logvar [B,Z] (either may be NULL); the decoder does not run. */
+int  shm_vae_encode(shm_vae_plan* plan, const float* x, float* mu, float* logvar,
+                    int32_t train_mode, uint64_t drop_seed, void* workspace, void* stream);
+/* TemporalVAE.decode (temporal_vae.py:65-70): z[B,Z] -> recon[B,T,D] with T = the plan's window length (the reference's seq_len
+ * argument); the encoder does not run.  Neither call leaves state for shm_vae_backward. */
+int  shm_vae_decode(shm_vae_plan* plan, const float* z, float* recon,
+                    int32_t train_mode, uint64_t drop_seed, void* workspace, void* stream);
+
 /* On-device windowing + normalisation: out[n][t][d] = nan_to_num((series[starts[n]+t][d] - mean[d]) / std[d]),
  * i.e. make_windows + normalize of 4DOF/Scripts/03_train_vae.py:98-117 (dup. 04:73-110, 05:76-115, 06:91-126) without the T-fold
  * host copy: series [n_rows, D] fp32 and starts [N] int32 are device buffers; every starts[n] must satisfy
@@ -94,9 +111,16 @@ int  shm_window_gather(const float* series, int64_t n_rows, int32_t D, const int
 
 /* Health of the layer-pipelined launches (bf16 path, 2 layers: both LSTM layers of a stack run in ONE launch, the upper
  * layer consuming the lower layer's h_t a few steps behind through in-launch flags).  Synchronises the stream.  SHM_OK, or
- * SHM_ESTATE if a consumer workgroup ever gave up waiting (results since the last shm_vae_pack_weights are then invalid).
+ * SHM_ESTATE if a consumer workgroup ever gave up waiting (the word is sticky: every result since its last reset is then invalid).
  * No reference counterpart: nn.LSTM (temporal_vae.py:32,44) hides its layer loop. */
 int  shm_vae_plan_status(const shm_vae_plan* plan, const void* workspace, void* stream);
+/* The same word without a host synchronisation: copies the plan's sticky status word (0 = healthy) into dst (device, 4 bytes) on the
+ * stream, so a trainer can carry it in the statistics buffer it reads back anyway.  The word is cleared by the FIRST shm_vae_pack_weights
+ * on a plan (the workspace arrives uninitialised) and by shm_vae_plan_reset_status only: re-packing the weights after an optimiser step
+ * does not clear it.  shm_vae_plan_status_offset: byte offset of the word inside the workspace (-1: this plan has no such word). */
+int  shm_vae_plan_status_word(const shm_vae_plan* plan, const void* workspace, uint32_t* dst, void* stream);
+int64_t shm_vae_plan_status_offset(const shm_vae_plan* plan);
+int  shm_vae_plan_reset_status(shm_vae_plan* plan, void* workspace, void* stream);
 /* Measurement / test knob: 0 = one launch per LSTM layer, 1 = layer-pipelined launches (default; also SHM_PAIR_LAUNCH=0 in
  * the environment).  Returns the previous setting.  Both settings give bit-identical results. */
 int  shm_set_pair_launch(int on);

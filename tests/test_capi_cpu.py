@@ -56,6 +56,44 @@ def test_invalid_configs_are_rejected_with_a_message():
     _capi.lib.shm_vae_plan_destroy(handle)
 
 
+@pytest.mark.parametrize("field,value,word", [("hidden_dim", 48, "hidden_dim"), ("hidden_dim", 256, "hidden_dim"), ("latent_dim", 33, "latent_dim"),
+                                              ("latent_dim", 0, "latent_dim"), ("num_layers", 3, "num_layers"), ("num_layers", 0, "num_layers"),
+                                              ("input_dim", 17, "input_dim"), ("precision", 7, "precision"), ("dropout", 1.0, "dropout")])
+def test_unsupported_shapes_return_einval_with_a_message(field, value, word):
+    """The reference constructor accepts any sizes (temporal_vae.py:14-21); this build supports H in {32, 64, 128}, Z <= 32, L <= 2,
+    D <= 16.  Outside that every entry point that takes a config returns SHM_EINVAL (-1) and shm_last_error() names the field;
+    the Python mirror turns it into an exception at construction."""
+    from shm_hip import _capi
+    c = _capi.make_config(4, 16, 128, 2, True, 0.3)
+    setattr(c, field, value)
+    handle = C.c_void_p(0)
+    assert _capi.lib.shm_vae_param_count(C.byref(c)) == -1
+    assert _capi.lib.shm_vae_param_layout(C.byref(c), None, 0) == -1
+    assert _capi.lib.shm_vae_plan_create(C.byref(c), 8, 16, 0, C.byref(handle)) == -1 and not handle.value
+    msg = _capi.lib.shm_last_error().decode()
+    assert word in msg and len(msg) > len(word), msg
+    if field != "precision":
+        from Scripts.Models.temporal_vae import TemporalVAE
+        kw = dict(input_dim=4, latent_dim=16, hidden_dim=128, num_layers=2, dropout=0.3)
+        kw[field] = value
+        with pytest.raises((RuntimeError, ValueError), match=word):     # ValueError: torch's own nn.LSTM check (num_layers 0), as in the reference
+            TemporalVAE(**kw)
+
+
+def test_eps_counter_rng_replica_statistics():
+    """shm_eps_normal: host replica of the head kernel's reparameterisation-noise stream — standard normal, stream-separated."""
+    from shm_hip import _capi
+    n = 1 << 16
+    a = np.zeros(n, np.float32); b = np.zeros(n, np.float32); c2 = np.zeros(n, np.float32)
+    _capi.lib.shm_eps_normal(C.c_uint64(42), C.c_uint64(1), n, a.ctypes.data_as(C.c_void_p))
+    _capi.lib.shm_eps_normal(C.c_uint64(42), C.c_uint64(2), n, b.ctypes.data_as(C.c_void_p))
+    _capi.lib.shm_eps_normal(C.c_uint64(42), C.c_uint64(1), n, c2.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(a, c2) and not np.array_equal(a, b)
+    assert abs(a.mean()) < 0.02 and abs(a.std() - 1.0) < 0.02 and abs(np.corrcoef(a, b)[0, 1]) < 0.02
+    assert abs((np.abs(a) > 1.959964).mean() - 0.05) < 0.005 and np.isfinite(a).all() and np.abs(a).max() < 6.5
+    assert abs(np.corrcoef(a[:-1], a[1:])[0, 1]) < 0.02
+
+
 def test_dropout_mask_replica_statistics():
     from shm_hip import _capi
     buf = np.zeros(64 * 50 * 32, dtype=np.uint8)

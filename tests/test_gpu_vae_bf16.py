@@ -242,3 +242,49 @@ def test_bf16_pipelined_handoff_under_memory_load():
         side.synchronize()
         for u, v in zip(ref, got):
             assert torch.equal(u, v), (rep, float((u - v).abs().max()))
+
+
+def test_handoff_status_word_is_sticky_and_fails_loudly():
+    """A consumer workgroup that gives up waiting sets a status word in the plan's workspace and finishes with garbage.  That word
+    must (i) survive the weight re-packing of every optimiser step, (ii) arrive in the trainer's statistics buffer without extra
+    synchronisation and (iii) make the run fail loudly a few steps later — here the word is forced by writing it into the workspace."""
+    from Scripts.Models.temporal_vae import TemporalVAE
+    from shm_hip._capi import lib
+    from shm_hip.pipeline import score_windows
+    from shm_hip.trainer import VAETrainer
+    torch.manual_seed(3)
+    m = TemporalVAE(4, 16, 128, 2, 0.0, precision="bf16").cuda().train()
+    tr = VAETrainer(m, lr=1e-3, weight_decay=0.0, max_norm=2.0)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(8, 16, 4, generator=g).cuda()
+    for _ in range(3):
+        s = tr.step(x, 0.5).cpu().numpy()
+        tr.check(s)                                              # healthy: no exception, word == 0
+    assert int(s.view(np.uint32)[4]) == 0
+    pl = tr.engine.last_plan
+    off = int(lib.shm_vae_plan_status_offset(pl.handle))
+    assert off >= 0
+    pl.ws[off:off + 4].view(torch.int32).fill_(0x80000005 - (1 << 32))      # "the consumer of tile 4 (backward) gave up"
+    raised_in_step = False
+    try:
+        for _ in range(4):                                       # several packs later the word must still be there
+            s = tr.step(x, 0.5).cpu().numpy()
+    except RuntimeError as e:
+        raised_in_step = "hand-off timeout" in str(e)
+    assert raised_in_step, "VAETrainer.step did not raise on a set status word"
+    assert int(tr.stats.cpu().numpy().view(np.uint32)[4]) == 0x80000005
+    with pytest.raises(RuntimeError, match="hand-off timeout"):
+        tr.check(tr.stats.cpu().numpy())
+    with pytest.raises(RuntimeError, match="gave up waiting"):
+        tr.engine.check_status()
+    tr.engine.reset_status()
+    tr.engine.check_status()
+    # inference plans: the scoring loop of the stage scripts checks once per call
+    m.eval()
+    sc = score_windows(m, x, batch=8)
+    assert torch.isfinite(sc).all()
+    pli = tr.engine.last_plan
+    offi = int(lib.shm_vae_plan_status_offset(pli.handle))
+    pli.ws[offi:offi + 4].view(torch.int32).fill_(7)
+    with pytest.raises(RuntimeError, match="gave up waiting"):
+        score_windows(m, x, batch=8)
