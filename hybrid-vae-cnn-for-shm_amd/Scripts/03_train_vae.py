@@ -1,5 +1,5 @@
 """Stage 1 on MI355X — counterpart of reference 4DOF/Scripts/03_train_vae.py (constants :27-47; plotting omitted).
-    python -m Scripts.03_train_vae --root /path/to/4DOF [--precision bf16]
+    python -m Scripts.03_train_vae --root /path/to/4DOF [--precision split|fp32|bf16]
 --root is a directory laid out like the reference's 4DOF/ (Data/processed/run_splits.json + the CSV runs)."""
 import argparse
 import json
@@ -22,7 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--root", required=True)
     ap.add_argument("--epochs", type=int, default=50)
-    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32")
+    ap.add_argument("--precision", choices=["split", "fp32", "bf16"], default="split", help="arithmetic of the VAE kernels: split (default) = bf16 hi+lo operand pairs, holds the reference's fp32 results to 1e-4 at bf16 matrix rates; fp32 = exact-f32 MFMA; bf16 = throughput path with its own tolerances")
     a = ap.parse_args()
     root = Path(a.root)
     splits = json.loads((root / "Data/processed/run_splits.json").read_text())

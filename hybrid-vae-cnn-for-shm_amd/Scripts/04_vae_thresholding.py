@@ -20,11 +20,13 @@ HEALTHY_FRAC = (0.4, 0.7)
 
 
 def main():
-    ap = argparse.ArgumentParser(); ap.add_argument("--root", required=True); a = ap.parse_args()
+    ap = argparse.ArgumentParser(); ap.add_argument("--root", required=True)
+    ap.add_argument("--precision", choices=["split", "fp32", "bf16"], default="split", help="arithmetic of the VAE kernels: split (default) = bf16 hi+lo operand pairs, holds the reference's fp32 results to 1e-4 at bf16 matrix rates; fp32 = exact-f32 MFMA; bf16 = throughput path with its own tolerances")
+    a = ap.parse_args()
     root = Path(a.root)
     splits = json.loads((root / "Data/processed/run_splits.json").read_text())
     st = np.load(root / "Data/processed/normal_stats.npz")
-    vae = TemporalVAE(NUM_FEATURES, 16, 128, 2, 0.3).to("cuda")
+    vae = TemporalVAE(NUM_FEATURES, 16, 128, 2, 0.3, precision=a.precision).to("cuda")
     vae.load_state_dict(torch.load(root / "models/temporal_vae_state_dict.pt", map_location="cuda"))
     Zn = dataprep.normalize_windows(dataprep.fraction_windows(splits["normal"]["files"], HEALTHY_FRAC, SEQ_LEN, NUM_FEATURES, 1, root), st["mean"], st["std"])
     thr, scores = workflows.vae_threshold(vae, Zn, root / "Data/processed")

@@ -19,13 +19,14 @@ from shm_hip import dataprep, workflows                      # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--root", required=True); ap.add_argument("--epochs", type=int, default=100)
+    ap.add_argument("--precision", choices=["split", "fp32", "bf16"], default="split", help="arithmetic of the VAE kernels: split (default) = bf16 hi+lo operand pairs, holds the reference's fp32 results to 1e-4 at bf16 matrix rates; fp32 = exact-f32 MFMA; bf16 = throughput path with its own tolerances")
     a = ap.parse_args()
     root = Path(a.root)
     splits = json.loads((root / "Data/processed/run_splits.json").read_text())
     if splits.get("mode") != "window_level_per_file":
         raise RuntimeError("run_splits.json must be window_level_per_file")
     st = np.load(root / "Data/processed/normal_stats.npz")
-    vae = TemporalVAE(NUM_FEATURES, 16, 128, 2, 0.3).to("cuda")
+    vae = TemporalVAE(NUM_FEATURES, 16, 128, 2, 0.3, precision=a.precision).to("cuda")
     vae.load_state_dict(torch.load(root / "models/temporal_vae_state_dict.pt", map_location="cuda"))
     data = {}
     for split in ("train", "val"):

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <functional>
 #include <map>
 #include <new>
 #include <string>
@@ -75,6 +76,12 @@ struct shm_vae_plan {
     // call-order state
     bool packed, fwd_saved, loss_done, drop_active;
     bool err_armed;         // the sticky hand-off error word has been cleared once (first pack_weights on this plan / explicit reset)
+    // split path: the deferred weight-gradient products of a layer run on a side stream of the plan, beside the next layer's recurrence
+    // (a recurrent launch holds one workgroup on 128 of the 256 CUs).  Created on the first backward; two dpre plane sets alternate.
+    hipStream_t side;
+    hipEvent_t ev_fork, ev_join, ev_rec[4];
+    bool side_ready;
+    size_t dpre_set[4], dpre_set_lo[4], dpre_set_tsum[4];   // split path: dpre hi / lo planes and sum_t dpre per (stack, layer)
     int sync_next;          // which of the two pair-launch sync blocks is all-zero and goes to the next pair launch
     uint64_t drop_seed;
     float* recon_ptr;       // where the last forward left recon (caller buffer or workspace)
@@ -281,8 +288,16 @@ extern "C" int shm_vae_plan_create(const shm_vae_config* cfg, int32_t B, int32_t
         p->dyx = take((size_t)B * H); p->dy = take((size_t)B * H); p->dh_last = take((size_t)B * H); p->dh0 = take((size_t)B * H);
         p->recon = take(BT * D); p->d_recon = take(BT * D); p->d_mu = take((size_t)B * Z); p->d_lv = take((size_t)B * Z);
         p->dpre_seq = bf ? take_bytes(2 * Rq * 4 * H) : take(BT * 4 * H);   // bf16: whole tiles (unconditional stores)
-        if (sp) p->dpre_lo = take_bytes(2 * Rq * 4 * H);
         p->dx_seq = take(bf ? Rq * H : BT * H); p->dpre_tsum = take((size_t)B * 4 * H);
+        if (sp) {
+            p->dpre_lo = take_bytes(2 * Rq * 4 * H);
+            for (int k = 0; k < 4; ++k) {
+                if ((k & 1) >= L) continue;                       // set = stack * 2 + layer
+                p->dpre_set[k] = k == 0 ? p->dpre_seq : take_bytes(2 * Rq * 4 * H);
+                p->dpre_set_lo[k] = k == 0 ? p->dpre_lo : take_bytes(2 * Rq * 4 * H);
+                p->dpre_set_tsum[k] = k == 0 ? p->dpre_tsum : take((size_t)B * 4 * H);
+            }
+        }
         if (bf && !sp && L == 2) { p->dpre_seq2 = take_bytes(2 * Rq * 4 * H); p->dpre_tsum2 = take((size_t)B * 4 * H); }
         size_t gp = 0;
         auto upd = [&](int R, int M, int N) { const size_t e = gemm_tn_partial_elems(R, M, N); if (e > gp) gp = e; };
@@ -313,7 +328,31 @@ extern "C" int shm_vae_plan_create(const shm_vae_config* cfg, int32_t B, int32_t
     return SHM_OK;
 }
 
-extern "C" void shm_vae_plan_destroy(shm_vae_plan* plan) { delete plan; }
+extern "C" void shm_vae_plan_destroy(shm_vae_plan* plan) {
+    if (plan && plan->side_ready) {
+        (void)hipStreamSynchronize(plan->side);
+        (void)hipEventDestroy(plan->ev_fork); (void)hipEventDestroy(plan->ev_join);
+        for (auto& e : plan->ev_rec) (void)hipEventDestroy(e);
+        (void)hipStreamDestroy(plan->side);
+    }
+    delete plan;
+}
+
+static int ensure_side_stream(shm_vae_plan* p) {
+    if (p->side_ready) return SHM_OK;
+    SHM_HIP_CHECK(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+    SHM_HIP_CHECK(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+    SHM_HIP_CHECK(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+    for (auto& e : p->ev_rec) SHM_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    p->side_ready = true;
+    return SHM_OK;
+}
+// SHM_SIDE_STREAM=0: everything on the caller's stream (A/B measurements; results are bit-identical either way)
+static bool side_stream_enabled() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("SHM_SIDE_STREAM"); on = (e && e[0] == '0') ? 0 : 1; }
+    return on != 0;
+}
 extern "C" size_t shm_vae_plan_workspace_bytes(const shm_vae_plan* plan) { return plan ? plan->ws_bytes : 0; }
 
 static int check_ws(const shm_vae_plan* p, const void* ws) {
@@ -651,6 +690,15 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
 
     const bool sp = c.precision == SHM_PREC_SPLIT;
     const bool bf = c.precision == SHM_PREC_BF16 || sp;
+    // gs: the stream of the deferred weight-gradient products.  Split path: the plan's side stream, forked from / joined to s with events
+    const bool use_side = sp && side_stream_enabled();
+    hipStream_t gs = s;
+    if (use_side) {
+        if ((rc = ensure_side_stream(p))) return rc;
+        gs = p->side;
+        SHM_HIP_CHECK(hipEventRecord(p->ev_fork, s));
+        SHM_HIP_CHECK(hipStreamWaitEvent(gs, p->ev_fork, 0));
+    }
     // wide products on bf16 operands: dW_ih = dpre^T x_in (dropout re-applied) and dW_hh = dpre^T h_{t-1} in ONE launch (A read once)
     // lo planes of the split path: {A, Bin, Bh, Bx}
     struct LoPlanes { const void* A; const void* Bin; const void* Bh; const void* Bx; };
@@ -668,7 +716,7 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
         g.drop_p = dp; g.drop_seed = p->drop_seed; g.drop_stack = stack;
         g.partial = part ? part : at<float>(ws, p->gemm_partial); g.partial_elems = p->gemm_partial_elems;
         g.zeros = at<char>(ws, p->misc + 64);
-        return launch_gemm_tn_bf16(g, s, defer);
+        return launch_gemm_tn_bf16(g, gs, defer);
     };
     auto gemm = [&](const void* A, int lda, int M, const void* Bm, int ldb, int N, int R, float* C, int shift_T, int trans_out,
                     float dp, uint32_t stack, int a_bf16 = 0, int b_bf16 = 0, ReduceJobs* defer = nullptr, float* part = nullptr) -> int {
@@ -678,7 +726,7 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
         g.A = A; g.lda = lda; g.Bm = Bm; g.ldb = ldb; g.C = C; g.ldc = trans_out ? M : N; g.R = R; g.M = M; g.N = N;
         g.shift_T = shift_T; g.trans_out = trans_out; g.drop_p = dp; g.drop_seed = p->drop_seed; g.drop_stack = stack;
         g.partial = part ? part : at<float>(ws, p->gemm_partial); g.partial_elems = p->gemm_partial_elems;
-        return launch_gemm_tn_f32(g, s, defer);
+        return launch_gemm_tn_f32(g, gs, defer);
     };
 
     // output layer (temporal_vae.py:70): dW_out[d][k] = sum_r d_recon[r][d] h[r][k]
@@ -687,12 +735,19 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
     ReduceJobs rjobs;                    // pair path: every reduction of a stack in ONE launch at the end of the stack
     rjobs.n = 0;
     {
-        KernelTimer kt("dw_gemm.out", s);
+        KernelTimer kt("dw_gemm.out", gs);
         if ((rc = launch_narrow_tn(h_top, bf ? 1 : 0, H, H, d_recon, D, bf ? ceil_div(B, SHM_WPT) * SHM_WPT * T : BT, grads + p->out_w, 0, grads + p->out_b,
-                                   at<float>(ws, p->narrow_scratch2), s, bf ? T : 0, bf ? B : 0, pair_bwd ? &rjobs : nullptr,
+                                   at<float>(ws, p->narrow_scratch2), gs, bf ? T : 0, bf ? B : 0, pair_bwd ? &rjobs : nullptr,
                                    sp ? at<char>(ws, p->dec[L - 1].h_lo) : nullptr))) return rc;
     }
 
+    // split path: weight-gradient products waiting to be enqueued on the side stream (see run_stack_bwd)
+    std::vector<std::function<int()>> deferred;
+    auto flush_deferred = [&]() -> int {
+        for (auto& f : deferred) { const int r = f(); if (r) { deferred.clear(); return r; } }
+        deferred.clear();
+        return SHM_OK;
+    };
     auto run_stack_bwd = [&](LayerInst* st, uint32_t stack, const float* x0, bool is_dec) -> int {
         const int Rt = ceil_div(B, SHM_WPT) * SHM_WPT * T;   // bf16 rows incl. tile padding (padding rows of dpre are exactly zero)
         auto bwd_args_bf = [&](int l, bf16_t* dps, float* tsum) {
@@ -745,10 +800,13 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
             return launch_reduce_partials(tsum, B, (size_t)G, grads + st[l].b_ih, grads + st[l].b_hh, s);
         };
         if (sp) {
-            bf16_t* dph = at<bf16_t>(ws, p->dpre_seq); bf16_t* dpl = at<bf16_t>(ws, p->dpre_lo);
             const char* sn = stack == 0 ? "enc" : "dec";
             for (int l = L - 1; l >= 0; --l) {
                 char nm[32];
+                // one dpre plane set per (stack, layer): the side stream may still be reading a layer's dpre when later recurrences run
+                const int set = (int)stack * 2 + l;
+                bf16_t* dph = at<bf16_t>(ws, p->dpre_set[set]); bf16_t* dpl = at<bf16_t>(ws, p->dpre_set_lo[set]);
+                float* tsum = at<float>(ws, p->dpre_set_tsum[set]);
                 LstmBwdArgsS a;
                 memset(&a, 0, sizeof(a));
                 a.rec4 = at<float>(ws, st[l].saved); a.rec2 = at<float>(ws, st[l].saved_c);
@@ -757,7 +815,7 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
                     else a.dh_last = hb.dh_last;
                 } else a.dh_seq = dx_seq;
                 a.WhT_hi = at<bf16_t>(ws, st[l].WhT); a.WhT_lo = at<bf16_t>(ws, st[l].WhT_lo);
-                a.dpre_hi = dph; a.dpre_lo = dpl; a.dpre_tsum = dpre_tsum; a.B = B; a.T = T;
+                a.dpre_hi = dph; a.dpre_lo = dpl; a.dpre_tsum = tsum; a.B = B; a.T = T;
                 int r;
                 {
                     snprintf(nm, sizeof(nm), "lstm_bwd.%s%d", sn, l);
@@ -765,6 +823,9 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
                     r = launch_lstm_bwd_sp(H, a, s);
                 }
                 if (r) return r;
+                // the recurrence is enqueued: NOW hand the previous layers' weight-gradient products to the side stream (a recurrent
+                // launch holds 128 CUs; enqueued first it gets them, and the GEMMs fill what is left instead of the other way round)
+                if ((r = flush_deferred())) return r;
                 if (l > 0) {              // gradient on the layer below's h_t, all steps at once
                     DxArgsS da;
                     memset(&da, 0, sizeof(da));
@@ -774,30 +835,39 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
                     KernelTimer kt(nm, s);
                     if ((r = launch_dx_sp(H, da, s))) return r;
                 }
-                snprintf(nm, sizeof(nm), "dw_gemm.%s%d", sn, l);
-                KernelTimer kt(nm, s);
-                LoPlanes lo;
-                lo.A = dpl; lo.Bh = at<char>(ws, st[l].h_lo); lo.Bin = nullptr; lo.Bx = nullptr;
-                if (l > 0) {
-                    const bool dr = drop > 0.f;
-                    const void* xin = dr ? at<char>(ws, st[l].xdrop) : at<char>(ws, st[l - 1].h_seq);
-                    lo.Bin = dr ? at<char>(ws, st[l].xdrop_lo) : at<char>(ws, st[l - 1].h_lo);
-                    if ((r = gemm_bf(dph, G, xin, grads + st[l].w_ih, 0.f, stack, at<char>(ws, st[l].h_seq), grads + st[l].w_hh, Rt, nullptr, nullptr,
-                                     nullptr, nullptr, &lo))) return r;
-                } else if (st[l].in_const) {
-                    if ((r = gemm_bf(dph, G, nullptr, nullptr, 0.f, 0, at<char>(ws, st[l].h_seq), grads + st[l].w_hh, Rt, nullptr, nullptr,
-                                     nullptr, nullptr, &lo))) return r;
-                    // dW_ih = (sum_t dpre_t)^T h0: B rows, exact fp32 (temporal_vae.py:68 repeats h0, so the T products collapse)
-                    if ((r = gemm(dpre_tsum, G, G, hb.h0, H, H, B, grads + st[l].w_ih, 0, 0, 0.f, 0))) return r;
-                } else {
-                    const bool xfuse = H == 128;      // dW_ih = dpre^T x as a 16-column third product of the same launch
-                    lo.Bx = at<char>(ws, p->x_tb_lo);
-                    if ((r = gemm_bf(dph, G, nullptr, nullptr, 0.f, 0, at<char>(ws, st[l].h_seq), grads + st[l].w_hh, Rt, nullptr, nullptr,
-                                     xfuse ? at<char>(ws, p->x_tb) : nullptr, xfuse ? grads + st[l].w_ih : nullptr, &lo))) return r;
-                    if (!xfuse && (r = launch_narrow_tn(dph, 1, G, G, x0, D, Rt, grads + st[l].w_ih, 1, nullptr, at<float>(ws, p->narrow_scratch), s, T, B,
-                                                        nullptr, dpl))) return r;
-                }
-                if ((r = launch_reduce_partials(dpre_tsum, B, (size_t)G, grads + st[l].b_ih, grads + st[l].b_hh, s))) return r;
+                hipEvent_t ev = nullptr;
+                if (use_side) { ev = p->ev_rec[set]; SHM_HIP_CHECK(hipEventRecord(ev, s)); }
+                const LayerInst* stp = st;
+                deferred.push_back([=, &gemm_bf, &gemm]() -> int {
+                    int r2;
+                    if (ev) SHM_HIP_CHECK(hipStreamWaitEvent(gs, ev, 0));
+                    char gnm[32];
+                    snprintf(gnm, sizeof(gnm), "dw_gemm.%s%d", sn, l);
+                    KernelTimer kt(gnm, gs);
+                    LoPlanes lo;
+                    lo.A = dpl; lo.Bh = at<char>(ws, stp[l].h_lo); lo.Bin = nullptr; lo.Bx = nullptr;
+                    if (l > 0) {
+                        const bool dr = drop > 0.f;
+                        const void* xin = dr ? at<char>(ws, stp[l].xdrop) : at<char>(ws, stp[l - 1].h_seq);
+                        lo.Bin = dr ? at<char>(ws, stp[l].xdrop_lo) : at<char>(ws, stp[l - 1].h_lo);
+                        if ((r2 = gemm_bf(dph, G, xin, grads + stp[l].w_ih, 0.f, stack, at<char>(ws, stp[l].h_seq), grads + stp[l].w_hh, Rt, nullptr, nullptr,
+                                          nullptr, nullptr, &lo))) return r2;
+                    } else if (stp[l].in_const) {
+                        if ((r2 = gemm_bf(dph, G, nullptr, nullptr, 0.f, 0, at<char>(ws, stp[l].h_seq), grads + stp[l].w_hh, Rt, nullptr, nullptr,
+                                          nullptr, nullptr, &lo))) return r2;
+                        // dW_ih = (sum_t dpre_t)^T h0: B rows, exact fp32 (temporal_vae.py:68 repeats h0, so the T products collapse)
+                        if ((r2 = gemm(tsum, G, G, hb.h0, H, H, B, grads + stp[l].w_ih, 0, 0, 0.f, 0))) return r2;
+                    } else {
+                        const bool xfuse = H == 128;      // dW_ih = dpre^T x as a 16-column third product of the same launch
+                        lo.Bx = at<char>(ws, p->x_tb_lo);
+                        if ((r2 = gemm_bf(dph, G, nullptr, nullptr, 0.f, 0, at<char>(ws, stp[l].h_seq), grads + stp[l].w_hh, Rt, nullptr, nullptr,
+                                          xfuse ? at<char>(ws, p->x_tb) : nullptr, xfuse ? grads + stp[l].w_ih : nullptr, &lo))) return r2;
+                        if (!xfuse && (r2 = launch_narrow_tn(dph, 1, G, G, x0, D, Rt, grads + stp[l].w_ih, 1, nullptr, at<float>(ws, p->narrow_scratch), gs, T, B,
+                                                             nullptr, dpl))) return r2;
+                    }
+                    return launch_reduce_partials(tsum, B, (size_t)G, grads + stp[l].b_ih, grads + stp[l].b_hh, gs);
+                });
+                if (!use_side && (r = flush_deferred())) return r;      // single stream: run it right away, as before
             }
             return SHM_OK;
         }
@@ -886,8 +956,9 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
     if ((rc = run_stack_bwd(p->dec, 1, nullptr, true))) return rc;
 
     // head: dpre_tsum still holds sum_t dpre of decoder layer 0
+    // (split path: decoder layer 0 wrote plane set 2)
     KernelTimer kt_head("head_bwd+grads", s);
-    if ((rc = launch_head_bwd(B, H, Z, c.layer_norm, dpre_tsum, prm + p->dec[0].w_ih, at<float>(ws, p->eps), d_mu, d_logvar,
+    if ((rc = launch_head_bwd(B, H, Z, c.layer_norm, sp ? at<float>(ws, p->dpre_set_tsum[2]) : dpre_tsum, prm + p->dec[0].w_ih, at<float>(ws, p->eps), d_mu, d_logvar,
                               head_params(p, prm), hb, s))) return rc;
     if ((rc = launch_head_grads(B, H, Z, c.layer_norm, hb, grads + p->l2h_w, grads + p->l2h_b, grads + p->mu_w, grads + p->mu_b,
                                 grads + p->lv_w, grads + p->lv_b, c.layer_norm ? grads + p->ln_w : nullptr,
@@ -895,6 +966,11 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
 
     kt_head.~KernelTimer(); kt_head.idx = -1;
     if ((rc = run_stack_bwd(p->enc, 0, x, false))) return rc;
+    if ((rc = flush_deferred())) return rc;
+    if (use_side) {                                          // join: everything after this call on s sees the complete gradient bucket
+        SHM_HIP_CHECK(hipEventRecord(p->ev_join, gs));
+        SHM_HIP_CHECK(hipStreamWaitEvent(s, p->ev_join, 0));
+    }
     return SHM_OK;
 }
 

@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(256) gemm_tn_bf16_kernel(GemmTnArgsB a, int ti
 //     SOURCE side: the 32-byte block b of row r lands in block b ^ f(r), f(r) = 4*((r>>3)&1) + (r&3), which makes the 8 rows
 //     a half-wave touches in one ds_read_b64_tr_b16 hit 8 different bank groups;
 //   * rows past the split end and the t = 0 rows of the shifted product read a zero line instead of being branched around.
-constexpr int V2_KC = 32, V2_NBUF = 4, V2_MT = 256;
+constexpr int V2_KC = 32, V2_NBUF = 4, V2_MT = 256, V2_CH = 2;
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_cvoid;
@@ -205,8 +205,20 @@ __global__ void __launch_bounds__(512) gemm_tn_bf16_v2_kernel(GemmTnArgsB a, int
     }
     auto issue = [&](int k) {                            // stage k -> ring slot k % NBUF (always issued: the counts stay static)
         char* buf = smem + (k & (V2_NBUF - 1)) * ST_BYTES;
-        const int seg = k / nst;                          // >= nseg for the over-issued tail stages: every row reads the zero line
-        const int r0 = seg < nseg ? r_begin + (k - seg * nst) * V2_KC : r_end;
+        // Split-precision operands: the three plane pairs of a CHUNK of V2_CH stages (64 rows) are walked back to back, so that the second
+        // read of A_hi (pairs 0 and 1) and of B_hi (pairs 0 and 2) is served by the XCD's L2 (32 workgroups x 64 KB per XCD) instead
+        // of HBM: the launch then moves A_hi + A_lo + B_hi + B_lo once, not three operand passes.  Over-issued tail stages
+        // (k >= total) read the zero line.
+        int seg = nseg, st = 0;
+        if (k < total) {
+            if (nseg == 1) { seg = 0; st = k; }
+            else {
+                const int full = nst / V2_CH, per = V2_CH * 3;
+                if (k < full * per) { const int c = k / per, r = k - c * per; seg = r / V2_CH; st = c * V2_CH + (r - seg * V2_CH); }
+                else { const int rem = nst - full * V2_CH, kk = k - full * per; seg = kk / rem; st = full * V2_CH + (kk - seg * rem); }
+            }
+        }
+        const int r0 = seg < nseg ? r_begin + st * V2_KC : r_end;
         const bf16_t* A = reinterpret_cast<const bf16_t*>(seg == 2 ? a.A_lo : a.A);
         const bool blo = seg == 1;
 #pragma unroll

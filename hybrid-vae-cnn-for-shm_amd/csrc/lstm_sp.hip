@@ -17,7 +17,10 @@
 //     (xproj_sp_kernel: full 16-column MFMA tiles, HBM-bound) and arrives as an fp32 stream in CELL ORDER (one f32x4
 //     {i,f,g,o} per lane and step); the constant-input decoder layer 0 reads its projection once; encoder layer 0
 //     (In <= 16: one 32-deep k-step) keeps its 8 input MFMAs in the loop;
-//   * BPTT records are fp32: {i,f,g,o} (16 B) + {c_{t-1}, tanh c_t} (8 B) per cell and step;
+//   * BPTT records are fp32: {i,f,g,o} (16 B) + {c_{t-1}, tanh c_t} (8 B) per cell and step.  Tried and not kept (round 2): 12-byte
+//     records with the gates as 16-bit fixed point and tanh(c_t) recomputed in the backward — the recurrences are latency-bound
+//     (~0.85 us per step), so halving their largest stream bought nothing (backward launch 0.218 -> 0.230 ms with the unpacking
+//     on the dependency chain, step 2.94 vs 2.93 ms) while the worst gradient tensor moved from 7e-6 to 2.7e-5 of its max;
 //   * backward: dpre_t leaves as hi / lo planes, dh_rec = W_hh^T dpre_t with the same column trick; dx = dpre W_ih of the
 //     layer below is the time-parallel dx_sp_kernel, weight gradients are gemm_tn_bf16.hip run over three plane pairs.
 #include "kernels.hpp"

@@ -42,6 +42,7 @@ def record_parity(test, case, errors):
     try:
         out.mkdir(exist_ok=True)
         with open(out / "parity_errors.jsonl", "a") as f:
-            f.write(json.dumps({"test": test, "case": case, "errors": errors}) + "\n")
+            clean = {k: (v if isinstance(v, (int, str)) else float(v)) for k, v in errors.items()}      # numpy scalars are not JSON types
+            f.write(json.dumps({"test": test, "case": case, "errors": clean}) + "\n")
     except OSError:
         pass

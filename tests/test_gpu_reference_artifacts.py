@@ -100,18 +100,24 @@ def test_reference_artifacts_on_reference_windows(ref_root, precision):
     print("reference artefacts", precision, json.dumps(got), "held:", json.dumps(ref))
     record_parity("reference_artifacts", precision, {**got, **{f"held_{k}": v for k, v in ref.items()}})
 
-    # Bands.  best-val total = recon + kl_w * KL at the best epoch (an early one: the KL weight is still near its floor there, so the
-    # value is mostly the validation reconstruction error of a ~300-step-old model): the eps / dropout streams move it by a few
-    # percent between seeds on OUR side (recorded in profiles/r02_reference_artifacts.json), so +-8 % of the held 0.65969.
-    assert abs(got["best_val_total"] - ref["best_val_total"]) < 0.08 * ref["best_val_total"], (got, ref)
-    assert 3 <= got["best_epoch"] <= 14, got                                               # held: 7; the minimum sits where the KL ramp starts to bite
-    # the normal-val score mean is an average over 2010 windows (stable); the P99 threshold is set by the ~20 largest of them under ONE
-    # eps draw (noisier): +-10 % and +-20 %.
-    assert abs(got["normal_val_mean"] - ref["normal_val_mean"]) < 0.10 * ref["normal_val_mean"], (got, ref)
-    assert abs(got["threshold"] - ref["threshold"]) < 0.20 * ref["threshold"], (got, ref)
-    # faults sit one to two orders of magnitude above the gate, as in the held summary (33.5 / 38.3 vs 0.65)
-    assert got["sensor_val_mean"] > 10 * got["threshold"] and got["structural_val_mean"] > 10 * got["threshold"], got
-    assert 0.5 < got["sensor_val_mean"] / ref["sensor_val_mean"] < 2.0 and 0.5 < got["structural_val_mean"] / ref["structural_val_mean"] < 2.0, (got, ref)
-    # CNN best validation cross-entropy: same order as the held 0.0974 (its inputs carry the VAE's residual channel, so it inherits the
-    # VAE run's randomness; ln 2 = 0.693 is an untrained classifier)
-    assert 0.02 < got["cnn_best_val_loss"] < 0.30, (got, ref)
+    # Bands.  Measured in round 2 (profiles/r02_parity_errors.json; split / fp32): best-val total 0.65846 / 0.65855 at epoch 8 / 7 against the
+    # held 0.65969 at epoch 7; normal-val mean 0.65091 / 0.65082 against 0.65131; P99 threshold 1.2908 / 1.2873 against 1.2814; sensor /
+    # structural means 33.2 / 38.3 against 33.5 / 38.3; CNN best-val CE 0.1136 / 0.1139 against 0.0974.  The initialisation and the epoch
+    # shuffles ARE the reference's (torch CPU generator, seed 42); what differs is the eps / dropout noise, whose effect on these
+    # aggregates turns out to be under one percent — the bands leave room for a different noise realisation, not for a wrong model:
+    # best-val total (= recon + kl_w * KL at an early epoch, mostly the validation reconstruction error): +-3 %.
+    assert abs(got["best_val_total"] - ref["best_val_total"]) < 0.03 * ref["best_val_total"], (got, ref)
+    assert 5 <= got["best_epoch"] <= 10, got                                               # held: 7; the minimum sits where the KL ramp starts to bite
+    # the normal-val score mean is an average over 2010 windows: +-3 %; the P99 threshold is set by the ~20 largest of them under ONE
+    # eps draw (noisier): +-6 %.
+    assert abs(got["normal_val_mean"] - ref["normal_val_mean"]) < 0.03 * ref["normal_val_mean"], (got, ref)
+    assert abs(got["normal_val_std"] - ref["normal_val_std"]) < 0.06 * ref["normal_val_std"], (got, ref)
+    assert abs(got["threshold"] - ref["threshold"]) < 0.06 * ref["threshold"], (got, ref)
+    # faults sit one to two orders of magnitude above the gate, as in the held summary (33.5 / 38.3 vs 0.65): +-10 % on their means
+    assert abs(got["sensor_val_mean"] - ref["sensor_val_mean"]) < 0.10 * ref["sensor_val_mean"], (got, ref)
+    assert abs(got["structural_val_mean"] - ref["structural_val_mean"]) < 0.10 * ref["structural_val_mean"], (got, ref)
+    # CNN best validation cross-entropy: its inputs carry the VAE's residual channel (one eps draw per window) and its own dropout /
+    # shuffle streams are torch's global RNG after a different call history, so "same order" is the honest claim: within a factor of
+    # two of the held 0.0974 (ln 2 = 0.693 is an untrained classifier)
+    assert 0.5 * ref["cnn_best_val_loss"] < got["cnn_best_val_loss"] < 2.0 * ref["cnn_best_val_loss"], (got, ref)
+    assert got["collapsed_epochs"] == 0
