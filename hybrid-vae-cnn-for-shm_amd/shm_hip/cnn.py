@@ -78,7 +78,7 @@ class CNNEngine:
             pl = self._plans[key] = _CnnPlan(self.cfg, key[0], key[1], self.flat.device)
         return pl
 
-    def forward(self, x, training_plan, train_mode, drop_seed=0):
+    def forward(self, x, training_plan, train_mode, drop_seed=0, want_logits=True):
         c = self.cfg
         if x.device.type != "cuda":
             raise RuntimeError("CNN (MI355X build): input must live on a CUDA (ROCm) device; there is no CPU path")
@@ -86,7 +86,8 @@ class CNNEngine:
             raise RuntimeError(f"expected x of shape [B, {c.in_channels}, {c.seq_len}, {c.num_features}], got {tuple(x.shape)}")
         x = x.contiguous().float()
         pl = self.plan(x.size(0), training_plan)
-        logits = torch.empty(x.size(0), c.num_classes, dtype=torch.float32, device=x.device)
+        # want_logits=False (fused train step): the logits stay in the workspace for shm_cnn_loss, no copy-out launch
+        logits = torch.empty(x.size(0), c.num_classes, dtype=torch.float32, device=x.device) if want_logits else None
         check(lib.shm_cnn_forward(pl.handle, _ptr(self.flat), _ptr(self.running), _ptr(x), _ptr(logits), int(bool(train_mode)),
                                   C.c_uint64(int(drop_seed) & (2 ** 64 - 1)), _ptr(pl.ws), _stream()), "shm_cnn_forward")
         self.last_plan = pl

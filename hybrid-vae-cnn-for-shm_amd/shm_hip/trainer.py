@@ -173,6 +173,8 @@ class CNNTrainer:
         self.stats = torch.zeros(2, dtype=torch.float32, device=dev)      # loss, grad_norm
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
         self.step_count = 0
+        self._nbt_pending = 0
+        model.register_state_dict_pre_hook(lambda module, prefix, keep_vars: self.flush_counters())
         self.comm = FlatAllReduce(group)
         rank = self.comm.dist.get_rank(group) if self.comm.world > 1 else 0
         self.seed = seed + 7919 * rank
@@ -196,7 +198,7 @@ class CNNTrainer:
         self.step_count += 1
         if drop_seed is None:
             drop_seed = (self.seed << 20) + self.step_count
-        _, pl, xc = eng.forward(x, training_plan=True, train_mode=True, drop_seed=drop_seed)
+        _, pl, xc = eng.forward(x, training_plan=True, train_mode=True, drop_seed=drop_seed, want_logits=False)
         eng.loss(pl, y.contiguous().to(torch.int64), self.stats)
         eng.backward(pl, xc, self.grads)
         scale = self.comm(self.grads)
@@ -205,14 +207,22 @@ class CNNTrainer:
                                 _ptr(self.exp_avg_sq), self.step_count, C.c_float(self.lr), C.c_float(b1), C.c_float(b2),
                                 C.c_float(self.eps), C.c_float(self.wd), C.c_float(0.0), C.c_float(scale),
                                 _ptr(self.scratch), C.c_void_p(self.stats.data_ptr() + 4), _stream()), "shm_adam_step")
-        self.model.conv1[1].num_batches_tracked += 1
-        self.model.conv2[1].num_batches_tracked += 1
+        # BatchNorm2d.num_batches_tracked (informational: momentum is the constant 0.1) is counted on the host and written into the two
+        # int64 buffers only when somebody looks (state_dict / evaluate): two ATen launches per step otherwise
+        self._nbt_pending += 1
         return self.stats
+
+    def flush_counters(self):
+        if self._nbt_pending:
+            self.model.conv1[1].num_batches_tracked += self._nbt_pending
+            self.model.conv2[1].num_batches_tracked += self._nbt_pending
+            self._nbt_pending = 0
 
     @torch.no_grad()
     def evaluate(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
         """Validation CrossEntropy of 05_train_cnn.py:284-292 (eval-mode forward, running statistics); device scalar."""
         self.sync_running_stats()
+        self.flush_counters()
         self.model.eval()
         logits = self.model(x)
         out = torch.empty(1, dtype=torch.float32, device=x.device)

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, split_prefix
+from conftest import load_golden, record_parity, split_prefix
 from test_gpu_vae import inject_eps, maxdiff
 
 pytestmark = pytest.mark.gpu
@@ -38,9 +38,14 @@ def test_forward_bf16(name):
     with inject_eps([torch.tensor(g["eps"])]):
         score = m.score(x)
     rel_score = float(np.abs(score.cpu().numpy() - g["score"]).max() / np.abs(g["score"]).max())
-    d = dict(recon=maxdiff(recon, g["recon"]), mu=maxdiff(mu, g["mu"]), logvar=maxdiff(lv, g["logvar"]), score_rel=rel_score)
+    d = dict(recon=maxdiff(recon, g["recon"]), mu=maxdiff(mu, g["mu"]), logvar=maxdiff(lv, g["logvar"]), score_rel=rel_score,
+             score_abs=maxdiff(score, g["score"]))
     print("bf16", name, json.dumps(d))
+    record_parity("forward_bf16", name, d)
     assert d["recon"] < 2e-3 and d["mu"] < 1e-2 and d["logvar"] < 1e-2 and rel_score < 5e-4, d
+    # the quantity north_star names — the per-window reconstruction score — is inside 1e-4 ABSOLUTE on this path too (it averages
+    # T*D squared errors, so the elementwise bf16 noise mostly cancels); elementwise recon / mu / logvar are not, hence the bars above
+    assert d["score_abs"] < 1e-4, d
 
 
 @pytest.mark.parametrize("name", ["vae_train_mini", "vae_train_1dof", "vae_train_openlab", "vae_train_ns_h128"])
