@@ -86,6 +86,9 @@ class TemporalVAE(nn.Module):
             # one 64-bit seed per call from torch's CPU generator: reproducible under torch.manual_seed
             drop_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         params = [named[name] for name, _, _ in eng.layout]
+        if x.size(0) == 0:
+            recon, mu, logvar, _, _, _ = eng.forward(x, eps, training_plan=False, train_mode=False)
+            return recon, mu, logvar
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
             return VAEFunction.apply(eng, x, eps, train_mode, drop_seed, *params)
         recon, mu, logvar, _, _, _ = eng.forward(x, eps, training_plan=False, train_mode=train_mode, drop_seed=drop_seed)

@@ -14,6 +14,10 @@
 
 #include "kernels.hpp"
 
+#ifndef SHM_SP_CHUNKS_DEFAULT
+#define SHM_SP_CHUNKS_DEFAULT 1
+#endif
+
 namespace shm {
 
 static thread_local char g_err[512] = "";
@@ -48,6 +52,7 @@ struct LayerInst {
     size_t xdrop = 0;                                    // bf16 path, layers >= 1: dropout-masked input sequence
     // split-precision path: the LO planes / LO fragment arrays that pair with the fields above, and the hoisted input projection
     size_t Wx_lo = 0, Wh_lo = 0, WhT_lo = 0, WxT_lo = 0, h_lo = 0, xdrop_lo = 0, xproj = 0;
+    size_t c_state = 0, b_state = 0;                     // split path, time-chunked launches: cell state / (dc, dh_rec) carried between chunks
 };
 
 }  // namespace shm
@@ -78,8 +83,8 @@ struct shm_vae_plan {
     bool err_armed;         // the sticky hand-off error word has been cleared once (first pack_weights on this plan / explicit reset)
     // split path: the deferred weight-gradient products of a layer run on a side stream of the plan, beside the next layer's recurrence
     // (a recurrent launch holds one workgroup on 128 of the 256 CUs).  Created on the first backward; two dpre plane sets alternate.
-    hipStream_t side;
-    hipEvent_t ev_fork, ev_join, ev_rec[4];
+    hipStream_t side, side2;
+    hipEvent_t ev_fork, ev_join, ev_join2, ev_rec[4], ev_chunk[16];
     bool side_ready;
     size_t dpre_set[4], dpre_set_lo[4], dpre_set_tsum[4];   // split path: dpre hi / lo planes and sum_t dpre per (stack, layer)
     int sync_next;          // which of the two pair-launch sync blocks is all-zero and goes to the next pair launch
@@ -244,6 +249,8 @@ extern "C" int shm_vae_plan_create(const shm_vae_config* cfg, int32_t B, int32_t
                 if (l > 0) li.xproj = take(Rq * 4 * H);                   // W_ih x_t + b of every step, cell order (whole tiles)
                 else if (li.in_const) li.xproj = take(qt * SHM_WPT * 4 * H);   // once per window
                 if (l > 0 && cfg->dropout > 0.f) { li.xdrop = take_bytes(2 * Rq * H); li.xdrop_lo = take_bytes(2 * Rq * H); }
+                li.c_state = take(qt * SHM_WPT * H);
+                if (training) li.b_state = take(2 * qt * SHM_WPT * H);
                 if (training) {
                     li.WhT = take_bytes(2 * bwd_pack_elems_bf16(H, H)); li.WhT_lo = take_bytes(2 * bwd_pack_elems_bf16(H, H));
                     if (l > 0) { li.WxT = take_bytes(2 * bwd_pack_elems_bf16(H, li.In)); li.WxT_lo = take_bytes(2 * bwd_pack_elems_bf16(H, li.In)); }
@@ -331,9 +338,11 @@ extern "C" int shm_vae_plan_create(const shm_vae_config* cfg, int32_t B, int32_t
 extern "C" void shm_vae_plan_destroy(shm_vae_plan* plan) {
     if (plan && plan->side_ready) {
         (void)hipStreamSynchronize(plan->side);
-        (void)hipEventDestroy(plan->ev_fork); (void)hipEventDestroy(plan->ev_join);
+        (void)hipStreamSynchronize(plan->side2);
+        (void)hipEventDestroy(plan->ev_fork); (void)hipEventDestroy(plan->ev_join); (void)hipEventDestroy(plan->ev_join2);
         for (auto& e : plan->ev_rec) (void)hipEventDestroy(e);
-        (void)hipStreamDestroy(plan->side);
+        for (auto& e : plan->ev_chunk) (void)hipEventDestroy(e);
+        (void)hipStreamDestroy(plan->side); (void)hipStreamDestroy(plan->side2);
     }
     delete plan;
 }
@@ -341,9 +350,12 @@ extern "C" void shm_vae_plan_destroy(shm_vae_plan* plan) {
 static int ensure_side_stream(shm_vae_plan* p) {
     if (p->side_ready) return SHM_OK;
     SHM_HIP_CHECK(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+    SHM_HIP_CHECK(hipStreamCreateWithFlags(&p->side2, hipStreamNonBlocking));
     SHM_HIP_CHECK(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
     SHM_HIP_CHECK(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+    SHM_HIP_CHECK(hipEventCreateWithFlags(&p->ev_join2, hipEventDisableTiming));
     for (auto& e : p->ev_rec) SHM_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& e : p->ev_chunk) SHM_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     p->side_ready = true;
     return SHM_OK;
 }
@@ -352,6 +364,21 @@ static bool side_stream_enabled() {
     static int on = -1;
     if (on < 0) { const char* e = getenv("SHM_SIDE_STREAM"); on = (e && e[0] == '0') ? 0 : 1; }
     return on != 0;
+}
+// Split path, 2-layer stacks: the window is cut into NC time chunks and the two layers run as a launch-level pipeline — layer 0 walks
+// chunk c+1 on the caller's stream while the side stream projects chunk c and runs layer 1 on it (a recurrent launch holds 128 of the
+// 256 CUs, so the two recurrences share the chip).  SHM_SP_CHUNKS=N (1 = off, the default: measured in round 2 at the north-star shape,
+// NC = 2 / 4 / 8 gave 179 / 182 / 151 k windows/s against 183 k unchunked — two recurrences side by side each slow from 57 to 85-90 us
+// per 64 steps because one of them already draws ~3 TB/s of record traffic).  Chunks are whole 16-row tiles: T % (4 NC) == 0.
+static int sp_chunks(const shm_vae_plan* p) {
+    const char* e = getenv("SHM_SP_CHUNKS");             // read per call: a test flips it inside one process
+    int want = e ? atoi(e) : SHM_SP_CHUNKS_DEFAULT;
+    if (want < 1) want = 1;
+    if (want > 8) want = 8;
+    if (p->cfg.precision != SHM_PREC_SPLIT || p->cfg.num_layers != 2 || !side_stream_enabled()) return 1;
+    int nc = want;
+    while (nc > 1 && (p->T % (4 * nc) != 0 || p->T / nc < 16)) --nc;
+    return nc;
 }
 extern "C" size_t shm_vae_plan_workspace_bytes(const shm_vae_plan* plan) { return plan ? plan->ws_bytes : 0; }
 
@@ -504,8 +531,75 @@ static int vae_forward_impl(shm_vae_plan* p, const float* x, const float* eps, c
     };
     // split-precision path: per layer [time-parallel input projection ->] recurrence with W_hh hi / lo in registers (lstm_sp.hip)
     const bool sp = c.precision == SHM_PREC_SPLIT;
+    const int NC = sp ? sp_chunks(p) : 1;
+    if (NC > 1 && (rc = ensure_side_stream(p))) return rc;
     auto run_stack_sp = [&](LayerInst* st, const float* in0, uint32_t stack, float* h_last) -> int {
         const int qt = ceil_div(B, SHM_WPT);
+        if (NC > 1) {
+            // launch-level layer pipeline over NC time chunks (see sp_chunks): s carries layer 0, the side stream projection + layer 1
+            const char* sn = stack == 0 ? "enc" : "dec";
+            char nm[32];
+            hipStream_t ss = p->side;
+            const int Tc = T / NC;
+            LstmFwdArgsS a0, a1;
+            memset(&a0, 0, sizeof(a0)); memset(&a1, 0, sizeof(a1));
+            for (int l = 0; l < 2; ++l) {
+                LstmFwdArgsS& a = l ? a1 : a0;
+                a.Wh_hi = at<bf16_t>(ws, st[l].Wh); a.Wh_lo = at<bf16_t>(ws, st[l].Wh_lo);
+                a.h_hi = at<bf16_t>(ws, st[l].h_seq); a.h_lo = at<bf16_t>(ws, st[l].h_lo);
+                a.rec4 = save ? at<float>(ws, st[l].saved) : nullptr; a.rec2 = save ? at<float>(ws, st[l].saved_c) : nullptr;
+                a.B = B; a.T = T; a.In = st[l].In; a.c_state = at<float>(ws, st[l].c_state);
+            }
+            a1.h_last = h_last; a1.mode = 0; a1.xproj = at<float>(ws, st[1].xproj);
+            if (!st[0].in_const) {
+                a0.mode = 2; a0.x = in0; a0.Wx_hi = at<bf16_t>(ws, st[0].Wx); a0.Wx_lo = at<bf16_t>(ws, st[0].Wx_lo); a0.bias = at<float>(ws, st[0].bsum);
+                if (save) { a0.x_hi = at<bf16_t>(ws, p->x_tb); a0.x_lo = at<bf16_t>(ws, p->x_tb_lo); }
+            } else {
+                XprojArgsS xa;
+                memset(&xa, 0, sizeof(xa));
+                xa.W_hi = at<bf16_t>(ws, st[0].Wx); xa.W_lo = at<bf16_t>(ws, st[0].Wx_lo); xa.bias = at<float>(ws, st[0].bsum);
+                xa.out = at<float>(ws, st[0].xproj);
+                int r = launch_split_planes(in0, (size_t)B * H, (size_t)qt * SHM_WPT * H, at<bf16_t>(ws, p->h0_bf), at<bf16_t>(ws, p->h0_lo), s);
+                if (r) return r;
+                xa.in_hi = at<bf16_t>(ws, p->h0_bf); xa.in_lo = at<bf16_t>(ws, p->h0_lo); xa.rows = qt * SHM_WPT;
+                snprintf(nm, sizeof(nm), "xproj.%s0", sn);
+                KernelTimer kt(nm, s);
+                if ((r = launch_xproj_sp(H, xa, s))) return r;
+                a0.mode = 1; a0.xproj = at<float>(ws, st[0].xproj);
+            }
+            XprojArgsS x1;
+            memset(&x1, 0, sizeof(x1));
+            x1.W_hi = at<bf16_t>(ws, st[1].Wx); x1.W_lo = at<bf16_t>(ws, st[1].Wx_lo); x1.bias = at<float>(ws, st[1].bsum);
+            x1.out = at<float>(ws, st[1].xproj);
+            x1.in_hi = at<bf16_t>(ws, st[0].h_seq); x1.in_lo = at<bf16_t>(ws, st[0].h_lo); x1.rows = qt * SHM_WPT * T;
+            x1.drop_p = drop; x1.drop_seed = drop_seed; x1.drop_stack = stack;
+            if (drop > 0.f) { x1.xd_hi = at<bf16_t>(ws, st[1].xdrop); x1.xd_lo = at<bf16_t>(ws, st[1].xdrop_lo); }
+            x1.cpt = Tc / 4; x1.seq_tiles = T / 4; x1.n_chunk_tiles = qt * x1.cpt;
+            for (int ch = 0; ch < NC; ++ch) {
+                int r;
+                a0.t0 = a1.t0 = ch * Tc; a0.t1 = a1.t1 = (ch + 1) * Tc;
+                {
+                    snprintf(nm, sizeof(nm), "lstm_fwd.%s0", sn);
+                    KernelTimer kt(nm, s);
+                    if ((r = launch_lstm_fwd_sp(H, a0, s))) return r;
+                }
+                hipEvent_t ev = p->ev_chunk[(int)stack * 8 + ch];
+                SHM_HIP_CHECK(hipEventRecord(ev, s));
+                SHM_HIP_CHECK(hipStreamWaitEvent(ss, ev, 0));
+                x1.tile_off = a0.t0 / 4;
+                {
+                    snprintf(nm, sizeof(nm), "xproj.%s1", sn);
+                    KernelTimer kt(nm, ss);
+                    if ((r = launch_xproj_sp(H, x1, ss))) return r;
+                }
+                snprintf(nm, sizeof(nm), "lstm_fwd.%s1", sn);
+                KernelTimer kt(nm, ss);
+                if ((r = launch_lstm_fwd_sp(H, a1, ss))) return r;
+            }
+            SHM_HIP_CHECK(hipEventRecord(p->ev_join, ss));
+            SHM_HIP_CHECK(hipStreamWaitEvent(s, p->ev_join, 0));
+            return SHM_OK;
+        }
         for (int l = 0; l < L; ++l) {
             const LayerInst& li = st[l];
             const char* sn = stack == 0 ? "enc" : "dec";
@@ -699,6 +793,7 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
         SHM_HIP_CHECK(hipEventRecord(p->ev_fork, s));
         SHM_HIP_CHECK(hipStreamWaitEvent(gs, p->ev_fork, 0));
     }
+    const int NCb = use_side ? sp_chunks(p) : 1;
     // wide products on bf16 operands: dW_ih = dpre^T x_in (dropout re-applied) and dW_hh = dpre^T h_{t-1} in ONE launch (A read once)
     // lo planes of the split path: {A, Bin, Bh, Bx}
     struct LoPlanes { const void* A; const void* Bin; const void* Bh; const void* Bx; };
@@ -799,6 +894,102 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
             if (defer) return reduce_jobs_add(*defer, tsum, B, (size_t)G, (size_t)G, grads + st[l].b_ih, grads + st[l].b_hh);
             return launch_reduce_partials(tsum, B, (size_t)G, grads + st[l].b_ih, grads + st[l].b_hh, s);
         };
+        // weight / bias gradients of split-path layer l from its dpre planes, on gs once `ev` has fired
+        auto defer_grads_sp = [&](int l, hipEvent_t ev) {
+            const char* sn = stack == 0 ? "enc" : "dec";
+            const int set = (int)stack * 2 + l;
+            bf16_t* dph = at<bf16_t>(ws, p->dpre_set[set]); bf16_t* dpl = at<bf16_t>(ws, p->dpre_set_lo[set]);
+            float* tsum = at<float>(ws, p->dpre_set_tsum[set]);
+            const LayerInst* stp = st;
+            deferred.push_back([=, &gemm_bf, &gemm]() -> int {
+                int r2;
+                if (ev) SHM_HIP_CHECK(hipStreamWaitEvent(gs, ev, 0));
+                char gnm[32];
+                snprintf(gnm, sizeof(gnm), "dw_gemm.%s%d", sn, l);
+                KernelTimer kt(gnm, gs);
+                LoPlanes lo;
+                lo.A = dpl; lo.Bh = at<char>(ws, stp[l].h_lo); lo.Bin = nullptr; lo.Bx = nullptr;
+                if (l > 0) {
+                    const bool dr = drop > 0.f;
+                    const void* xin = dr ? at<char>(ws, stp[l].xdrop) : at<char>(ws, stp[l - 1].h_seq);
+                    lo.Bin = dr ? at<char>(ws, stp[l].xdrop_lo) : at<char>(ws, stp[l - 1].h_lo);
+                    if ((r2 = gemm_bf(dph, G, xin, grads + stp[l].w_ih, 0.f, stack, at<char>(ws, stp[l].h_seq), grads + stp[l].w_hh, Rt, nullptr, nullptr,
+                                      nullptr, nullptr, &lo))) return r2;
+                } else if (stp[l].in_const) {
+                    if ((r2 = gemm_bf(dph, G, nullptr, nullptr, 0.f, 0, at<char>(ws, stp[l].h_seq), grads + stp[l].w_hh, Rt, nullptr, nullptr,
+                                      nullptr, nullptr, &lo))) return r2;
+                    // dW_ih = (sum_t dpre_t)^T h0: B rows, exact fp32 (temporal_vae.py:68 repeats h0, so the T products collapse)
+                    if ((r2 = gemm(tsum, G, G, hb.h0, H, H, B, grads + stp[l].w_ih, 0, 0, 0.f, 0))) return r2;
+                } else {
+                    const bool xfuse = H == 128;      // dW_ih = dpre^T x as a 16-column third product of the same launch
+                    lo.Bx = at<char>(ws, p->x_tb_lo);
+                    if ((r2 = gemm_bf(dph, G, nullptr, nullptr, 0.f, 0, at<char>(ws, stp[l].h_seq), grads + stp[l].w_hh, Rt, nullptr, nullptr,
+                                      xfuse ? at<char>(ws, p->x_tb) : nullptr, xfuse ? grads + stp[l].w_ih : nullptr, &lo))) return r2;
+                    if (!xfuse && (r2 = launch_narrow_tn(dph, 1, G, G, x0, D, Rt, grads + stp[l].w_ih, 1, nullptr, at<float>(ws, p->narrow_scratch), gs, T, B,
+                                                         nullptr, dpl))) return r2;
+                }
+                return launch_reduce_partials(tsum, B, (size_t)G, grads + stp[l].b_ih, grads + stp[l].b_hh, gs);
+            });
+        };
+        if (sp && NCb > 1) {
+            // launch-level layer pipeline over NCb time chunks, walking down in time: s carries layer 1, the plan's second side stream
+            // the dx product of a chunk and layer 0 on it; the weight-gradient products follow on gs once a layer's last chunk is done
+            const char* sn = stack == 0 ? "enc" : "dec";
+            hipStream_t ss = p->side2;
+            const int qt = ceil_div(B, SHM_WPT), Tc = T / NCb;
+            char nm[32];
+            LstmBwdArgsS b0, b1;
+            memset(&b0, 0, sizeof(b0)); memset(&b1, 0, sizeof(b1));
+            for (int l = 0; l < 2; ++l) {
+                LstmBwdArgsS& a = l ? b1 : b0;
+                const int set = (int)stack * 2 + l;
+                a.rec4 = at<float>(ws, st[l].saved); a.rec2 = at<float>(ws, st[l].saved_c);
+                a.WhT_hi = at<bf16_t>(ws, st[l].WhT); a.WhT_lo = at<bf16_t>(ws, st[l].WhT_lo);
+                a.dpre_hi = at<bf16_t>(ws, p->dpre_set[set]); a.dpre_lo = at<bf16_t>(ws, p->dpre_set_lo[set]);
+                a.dpre_tsum = at<float>(ws, p->dpre_set_tsum[set]); a.B = B; a.T = T;
+                a.state = at<float>(ws, st[l].b_state);
+            }
+            if (is_dec) { b1.dy = d_recon; b1.Wout = prm + p->out_w; b1.Dy = D; }
+            else b1.dh_last = hb.dh_last;
+            b0.dh_seq = dx_seq;
+            DxArgsS da;
+            memset(&da, 0, sizeof(da));
+            da.dpre_hi = b1.dpre_hi; da.dpre_lo = b1.dpre_lo; da.WxT_hi = at<bf16_t>(ws, st[1].WxT); da.WxT_lo = at<bf16_t>(ws, st[1].WxT_lo);
+            da.dx = dx_seq; da.rows = Rt; da.drop_p = drop; da.drop_seed = p->drop_seed; da.drop_stack = stack;
+            da.cpt = Tc / 4; da.seq_tiles = T / 4; da.n_chunk_tiles = qt * da.cpt;
+            // the side stream starts behind whatever s has done so far (head_bwd wrote dh_last; the previous stack's layer 0 read dx_seq)
+            SHM_HIP_CHECK(hipEventRecord(p->ev_fork, s));
+            SHM_HIP_CHECK(hipStreamWaitEvent(ss, p->ev_fork, 0));
+            for (int ch = NCb - 1; ch >= 0; --ch) {
+                int r;
+                b0.t0 = b1.t0 = ch * Tc; b0.t1 = b1.t1 = (ch + 1) * Tc;
+                {
+                    snprintf(nm, sizeof(nm), "lstm_bwd.%s1", sn);
+                    KernelTimer kt(nm, s);
+                    if ((r = launch_lstm_bwd_sp(H, b1, s))) return r;
+                }
+                if (ch == NCb - 1 && (r = flush_deferred())) return r;      // the previous stack's products, behind this stack's first recurrence
+                hipEvent_t ev = p->ev_chunk[(int)stack * 8 + ch];
+                SHM_HIP_CHECK(hipEventRecord(ev, s));
+                SHM_HIP_CHECK(hipStreamWaitEvent(ss, ev, 0));
+                da.tile_off = b0.t0 / 4;
+                {
+                    snprintf(nm, sizeof(nm), "dx_gemm.%s1", sn);
+                    KernelTimer kt(nm, ss);
+                    if ((r = launch_dx_sp(H, da, ss))) return r;
+                }
+                snprintf(nm, sizeof(nm), "lstm_bwd.%s0", sn);
+                KernelTimer kt(nm, ss);
+                if ((r = launch_lstm_bwd_sp(H, b0, ss))) return r;
+            }
+            // ev_chunk[stack*8 + 0] fired after layer 1's last chunk; layer 0's last chunk ends the side stream's work
+            defer_grads_sp(1, p->ev_chunk[(int)stack * 8]);
+            hipEvent_t ev0 = p->ev_rec[(int)stack * 2];
+            SHM_HIP_CHECK(hipEventRecord(ev0, ss));
+            SHM_HIP_CHECK(hipStreamWaitEvent(s, ev0, 0));       // head_bwd / the caller read layer 0's sum_t dpre and nothing may overtake dx_seq
+            defer_grads_sp(0, ev0);
+            return SHM_OK;
+        }
         if (sp) {
             const char* sn = stack == 0 ? "enc" : "dec";
             for (int l = L - 1; l >= 0; --l) {
@@ -837,36 +1028,7 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
                 }
                 hipEvent_t ev = nullptr;
                 if (use_side) { ev = p->ev_rec[set]; SHM_HIP_CHECK(hipEventRecord(ev, s)); }
-                const LayerInst* stp = st;
-                deferred.push_back([=, &gemm_bf, &gemm]() -> int {
-                    int r2;
-                    if (ev) SHM_HIP_CHECK(hipStreamWaitEvent(gs, ev, 0));
-                    char gnm[32];
-                    snprintf(gnm, sizeof(gnm), "dw_gemm.%s%d", sn, l);
-                    KernelTimer kt(gnm, gs);
-                    LoPlanes lo;
-                    lo.A = dpl; lo.Bh = at<char>(ws, stp[l].h_lo); lo.Bin = nullptr; lo.Bx = nullptr;
-                    if (l > 0) {
-                        const bool dr = drop > 0.f;
-                        const void* xin = dr ? at<char>(ws, stp[l].xdrop) : at<char>(ws, stp[l - 1].h_seq);
-                        lo.Bin = dr ? at<char>(ws, stp[l].xdrop_lo) : at<char>(ws, stp[l - 1].h_lo);
-                        if ((r2 = gemm_bf(dph, G, xin, grads + stp[l].w_ih, 0.f, stack, at<char>(ws, stp[l].h_seq), grads + stp[l].w_hh, Rt, nullptr, nullptr,
-                                          nullptr, nullptr, &lo))) return r2;
-                    } else if (stp[l].in_const) {
-                        if ((r2 = gemm_bf(dph, G, nullptr, nullptr, 0.f, 0, at<char>(ws, stp[l].h_seq), grads + stp[l].w_hh, Rt, nullptr, nullptr,
-                                          nullptr, nullptr, &lo))) return r2;
-                        // dW_ih = (sum_t dpre_t)^T h0: B rows, exact fp32 (temporal_vae.py:68 repeats h0, so the T products collapse)
-                        if ((r2 = gemm(tsum, G, G, hb.h0, H, H, B, grads + stp[l].w_ih, 0, 0, 0.f, 0))) return r2;
-                    } else {
-                        const bool xfuse = H == 128;      // dW_ih = dpre^T x as a 16-column third product of the same launch
-                        lo.Bx = at<char>(ws, p->x_tb_lo);
-                        if ((r2 = gemm_bf(dph, G, nullptr, nullptr, 0.f, 0, at<char>(ws, stp[l].h_seq), grads + stp[l].w_hh, Rt, nullptr, nullptr,
-                                          xfuse ? at<char>(ws, p->x_tb) : nullptr, xfuse ? grads + stp[l].w_ih : nullptr, &lo))) return r2;
-                        if (!xfuse && (r2 = launch_narrow_tn(dph, 1, G, G, x0, D, Rt, grads + stp[l].w_ih, 1, nullptr, at<float>(ws, p->narrow_scratch), gs, T, B,
-                                                             nullptr, dpl))) return r2;
-                    }
-                    return launch_reduce_partials(tsum, B, (size_t)G, grads + stp[l].b_ih, grads + stp[l].b_hh, gs);
-                });
+                defer_grads_sp(l, ev);
                 if (!use_side && (r = flush_deferred())) return r;      // single stream: run it right away, as before
             }
             return SHM_OK;

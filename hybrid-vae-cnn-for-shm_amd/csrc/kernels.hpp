@@ -216,6 +216,10 @@ struct LstmFwdArgsS {
     float* rec4; float* rec2;                     // BPTT records [tile][t][H/16][64] x {i,f,g,o} / {c_{t-1}, tanh c_t}, or nullptr
     bf16_t* x_hi; bf16_t* x_lo;                   // mode 2, optional: tile-blocked [rows,16] copies of x (dW_ih product)
     int B, T, In, mode;
+    // time chunk [t0, t1) of the window (t1 == 0: all of it).  A chunk with t0 > 0 continues from c_state (cell order [tile][H/16][64],
+    // written by the chunk before it) and from the h planes of step t0 - 1; a chunk with t1 < T leaves c_state for the next one.
+    int t0, t1;
+    float* c_state;
 };
 int launch_lstm_fwd_sp(int H, const LstmFwdArgsS& a, hipStream_t s);
 
@@ -227,6 +231,10 @@ struct LstmBwdArgsS {
     bf16_t* dpre_hi; bf16_t* dpre_lo;             // [rows, 4H] planes
     float* dpre_tsum;       // [B,4H]
     int B, T, Dy;
+    // time chunk: steps t1-1 .. t0 (t1 == 0: the whole window).  t1 < T: (dc, dh_rec) are taken from state ([tile][H/16][64] x f32x2, left by
+    // the chunk above) and sum_t dpre is ADDED to dpre_tsum; t0 > 0: state is written for the chunk below.
+    int t0, t1;
+    float* state;
 };
 int launch_lstm_bwd_sp(int H, const LstmBwdArgsS& a, hipStream_t s);
 
@@ -239,6 +247,9 @@ struct XprojArgsS {
     bf16_t* xd_hi; bf16_t* xd_lo;                 // dropout: the masked + rescaled input planes (operand of the dW_ih GEMM)
     int rows;
     float drop_p; uint64_t drop_seed; uint32_t drop_stack;
+    // time chunk of every window tile (cpt > 0): the launch covers n_chunk_tiles = tiles * cpt 16-row tiles; chunk-local tile k is the
+    // global tile (k / cpt) * seq_tiles + tile_off + k % cpt (seq_tiles = T / 4 tiles per window tile, tile_off = t0 / 4, cpt = (t1 - t0) / 4)
+    int cpt, seq_tiles, tile_off, n_chunk_tiles;
 };
 int launch_xproj_sp(int H, const XprojArgsS& a, hipStream_t s);
 struct DxArgsS {
@@ -247,6 +258,7 @@ struct DxArgsS {
     float* dx;                                    // fragment order [rows/16][H/16][64] x f32x4
     int rows;
     float drop_p; uint64_t drop_seed; uint32_t drop_stack;
+    int cpt, seq_tiles, tile_off, n_chunk_tiles;  // time chunk, as in XprojArgsS
 };
 int launch_dx_sp(int H, const DxArgsS& a, hipStream_t s);
 // fp32 [n_valid] -> bf16 planes hi, lo of n >= n_valid elements (the tail is zero-filled: padding windows of the last tile)

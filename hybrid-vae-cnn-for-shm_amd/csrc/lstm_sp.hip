@@ -65,6 +65,7 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_sp_kernel(LstmFwdArgsS a) {
     bf16_t* x_lds = smem_b + 2 * HBUF;          // [2][XBUF]   (mode 2)
 
     const int In = a.In > 0 ? a.In : 1, T = a.T, B = a.B, tile = blockIdx.x;
+    const int t0 = a.t0, t1 = a.t1;                                 // this launch walks steps [t0, t1) (a time chunk, or the whole window)
     const int tid = threadIdx.x, lane = tid & 63, ht = tid >> 6, q = lane >> 4, j = lane & 15;
     const int cj = j & 3, cr = j >> 2, cu = ht * 16 + q * 4 + cr;  // my cell: window cj of the tile, unit cu
     const int cb = tile * WPT + cj;
@@ -114,7 +115,7 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_sp_kernel(LstmFwdArgsS a) {
     const f32x4* xp = reinterpret_cast<const f32x4*>(a.xproj) + ((size_t)tile * (MODE == 1 ? 1 : T) * NW + ht) * 64 + lane;
     struct Slot { f32x4 v; };
     auto fetch = [&](Slot& X, int t) {           // mode 0: projection of step t; mode 2: x of step t; clamped, never predicated
-        const int tc = t < T ? t : T - 1;
+        const int tc = t < t1 ? t : t1 - 1;        // never reads another chunk's rows (they may be being written right now)
         if constexpr (MODE == 0) X.v = xp[(size_t)tc * NW * 64];
         else if constexpr (MODE == 2) X.v[0] = a.x[((size_t)xb0 * T + tc) * In + xk0];
     };
@@ -134,11 +135,18 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_sp_kernel(LstmFwdArgsS a) {
     if constexpr (MODE == 1) xconst = xp[0];
     if constexpr (MODE == 2) {
         __syncthreads();                          // images zeroed
-        x_commit(a.x[((size_t)xb0 * T) * In + xk0], 0, 0);
+        x_commit(a.x[((size_t)xb0 * T + t0) * In + xk0], t0, t0 & 1);
+    }
+    float c = 0.f, h = 0.f;
+    float* const cst = a.c_state ? a.c_state + ((size_t)tile * NW + ht) * 64 + lane : nullptr;
+    if (t0 > 0) {                                 // continue a previous chunk: c_{t0-1} from the state buffer, h_{t0-1} planes -> operand image
+        if (MODE != 2) __syncthreads();           // images zeroed
+        c = cst[0];
+        if (tid < 2 * NCH)
+            *reinterpret_cast<bf16x8*>(h_lds + (t0 & 1) * HBUF + f_img_off) = *reinterpret_cast<const bf16x8*>(f_dst + (size_t)(t0 - 1) * WPT * H);
     }
     __syncthreads();
 
-    float c = 0.f, h = 0.f;
     f32x4* sv4 = SAVE ? reinterpret_cast<f32x4*>(a.rec4) + ((size_t)tile * T * NW + ht) * 64 + lane : nullptr;
     f32x2* sv2 = SAVE ? reinterpret_cast<f32x2*>(a.rec2) + ((size_t)tile * T * NW + ht) * 64 + lane : nullptr;
     f32x4 r4_prev = {0.f, 0.f, 0.f, 0.f};
@@ -147,7 +155,7 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_sp_kernel(LstmFwdArgsS a) {
     auto step = [&](Slot& X, int t) {
         const int cur = t & 1;
         if constexpr (MODE != 1) asm volatile("" : "+v"(X.v));   // pin the consumption point of this slot (see lstm_bwd_bf16.hip)
-        if (t > 0) h_flush(t - 1, cur);           // h_{t-1} sits complete in h_lds[cur]
+        if (t > t0) h_flush(t - 1, cur);          // h_{t-1} sits complete in h_lds[cur]
         f32x4 acc[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -175,11 +183,11 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_sp_kernel(LstmFwdArgsS a) {
         __builtin_amdgcn_s_setprio(0);
         // h-independent vector work behind the MFMA issue: the record of step t-1, the staging of x_{t+1}
         if constexpr (SAVE) {
-            if (t > 0) { sv4[(size_t)(t - 1) * NW * 64] = r4_prev; sv2[(size_t)(t - 1) * NW * 64] = r2_prev; }
+            if (t > t0) { sv4[(size_t)(t - 1) * NW * 64] = r4_prev; sv2[(size_t)(t - 1) * NW * 64] = r2_prev; }
         }
         float gate[4];
         if constexpr (MODE == 2) {
-            if (t + 1 < T) x_commit(X.v[0], t + 1, cur ^ 1);
+            if (t + 1 < t1) x_commit(X.v[0], t + 1, cur ^ 1);
 #pragma unroll
             for (int g = 0; g < 4; ++g) gate[g] = redeal_hl(acc[g]) + bias_c[g];
             fetch(X, t + 4);
@@ -213,18 +221,19 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_sp_kernel(LstmFwdArgsS a) {
 
     Slot X0, X1, X2;
     constexpr int LEAD = MODE == 2 ? 1 : 0;       // mode 2 slots run one step ahead (x_{t+1} is staged during step t)
-    int t = 0;
-    for (int k = T % 3; k > 0; --k, ++t) { fetch(X0, t + LEAD); step(X0, t); }     // peel: the main loop runs whole triples
+    int t = t0;
+    for (int k = (t1 - t0) % 3; k > 0; --k, ++t) { fetch(X0, t + LEAD); step(X0, t); }     // peel: the main loop runs whole triples
     fetch(X0, t + LEAD); fetch(X1, t + 1 + LEAD); fetch(X2, t + 2 + LEAD);
     __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0) once: only steady-state loads cross the back-edge
-    for (; t + 2 < T; t += 3) {
+    for (; t + 2 < t1; t += 3) {
         step(X0, t);
         step(X1, t + 1);
         step(X2, t + 2);
     }
-    if constexpr (SAVE) { sv4[(size_t)(T - 1) * NW * 64] = r4_prev; sv2[(size_t)(T - 1) * NW * 64] = r2_prev; }
-    h_flush(T - 1, T & 1);
-    if (a.h_last && cvalid) a.h_last[(size_t)cb * H + cu] = h;
+    if constexpr (SAVE) { sv4[(size_t)(t1 - 1) * NW * 64] = r4_prev; sv2[(size_t)(t1 - 1) * NW * 64] = r2_prev; }
+    h_flush(t1 - 1, t1 & 1);
+    if (t1 < T) { if (cst) cst[0] = c; }
+    else if (a.h_last && cvalid) a.h_last[(size_t)cb * H + cu] = h;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -243,6 +252,7 @@ __global__ void __launch_bounds__(4 * H) lstm_bwd_sp_kernel(LstmBwdArgsS a) {
     float* wo_lds = reinterpret_cast<float*>(smem_b + 2 * PBUF);           // [Dy][H]
 
     const int T = a.T, B = a.B, Dy = a.Dy, tile = blockIdx.x;
+    const int t0 = a.t0, t1 = a.t1;                // this launch walks steps t1-1 down to t0 (a time chunk, or the whole window)
     const int tid = threadIdx.x, lane = tid & 63, ht = tid >> 6, q = lane >> 4, j = lane & 15;
     const int cj = j & 3, cr = j >> 2, cu = ht * 16 + q * 4 + cr;
     const int cb = tile * WPT + cj;
@@ -269,7 +279,7 @@ __global__ void __launch_bounds__(4 * H) lstm_bwd_sp_kernel(LstmBwdArgsS a) {
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     auto fetch = [&](PrefS& P, int t) {
-        const int tc = t < 0 ? 0 : t;
+        const int tc = t < t0 ? t0 : t;            // never reads another chunk's rows
         P.r4 = sv4[(size_t)tc * NW * 64];
         P.r2 = sv2[(size_t)tc * NW * 64];
         const size_t row = (size_t)bc * T + tc;
@@ -344,20 +354,26 @@ __global__ void __launch_bounds__(4 * H) lstm_bwd_sp_kernel(LstmBwdArgsS a) {
 
     __syncthreads();
     PrefS P0, P1, P2, P3;
-    if (a.dh_last) dh_rec = vmask * a.dh_last[(size_t)bc * H + cu];
-    int t = T - 1;
-    for (int k = T & 3; k > 0; --k, --t) { fetch(P0, t); step(P0, t); }
+    f32x2* const bst = a.state ? reinterpret_cast<f32x2*>(a.state) + ((size_t)tile * NW + ht) * 64 + lane : nullptr;
+    if (t1 < T) { const f32x2 st = bst[0]; dc = st[0]; dh_rec = st[1]; }      // continue the chunk above: (dc, dh_rec) of step t1
+    else if (a.dh_last) dh_rec = vmask * a.dh_last[(size_t)bc * H + cu];
+    int t = t1 - 1;
+    for (int k = (t1 - t0) & 3; k > 0; --k, --t) { fetch(P0, t); step(P0, t); }
     fetch(P0, t); fetch(P1, t - 1); fetch(P2, t - 2); fetch(P3, t - 3);
     __builtin_amdgcn_s_waitcnt(0x0F70);
-    for (; t >= 3; t -= 4) {
+    for (; t >= t0 + 3; t -= 4) {
         step(P0, t);
         step(P1, t - 1);
         step(P2, t - 2);
         step(P3, t - 3);
     }
-    if (cvalid && a.dpre_tsum) {
+    if (t0 > 0 && bst) bst[0] = f32x2{dc, dh_rec};
+    if (cvalid && a.dpre_tsum) {                   // sum_t dpre: the chunk that runs first (t1 == T) writes, later chunks add
 #pragma unroll
-        for (int g = 0; g < 4; ++g) a.dpre_tsum[(size_t)cb * 4 * H + g * H + cu] = tsum[g];
+        for (int g = 0; g < 4; ++g) {
+            float* d = a.dpre_tsum + (size_t)cb * 4 * H + g * H + cu;
+            *d = t1 < T ? *d + tsum[g] : tsum[g];
+        }
     }
 }
 
@@ -389,7 +405,9 @@ __global__ void __launch_bounds__(4 * H) xproj_sp_kernel(XprojArgsS a, int tiles
     for (int g = 0; g < 4; ++g) bias4[g] = *reinterpret_cast<const f32x4*>(a.bias + g * H + ht * 16 + q * 4);
     const uint32_t thr = drop_threshold(a.drop_p);
     const float dscale = DROP ? 1.0f / (1.0f - a.drop_p) : 1.0f;
-    const int R = a.rows, n_tiles = (R + 15) / 16;
+    // a time chunk of every window tile (cpt > 0): chunk-local 16-row tile k of the launch -> global tile (k / cpt) * seq_tiles + tile_off + k % cpt
+    const int R = a.rows, n_tiles = a.cpt > 0 ? a.n_chunk_tiles : (R + 15) / 16;
+    auto gtile = [&](int k) { return a.cpt > 0 ? (k / a.cpt) * a.seq_tiles + a.tile_off + (k % a.cpt) : k; };
     const int t0 = blockIdx.x * tiles_per_wg, t1 = min(n_tiles, t0 + tiles_per_wg);
     // staging: a 16-row tile = 16 x H bf16 per plane = 2H chunks of 16 B; chunk c of a plane -> (row c / (H/8), cols 8 (c % (H/8)))
     constexpr int CHP = 16 * H / 8;                       // chunks per plane (= NTHR / 2)
@@ -399,7 +417,7 @@ __global__ void __launch_bounds__(4 * H) xproj_sp_kernel(XprojArgsS a, int tiles
     const bf16x8 zero8 = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
     bf16x8 st, st2;                                       // DROP: every thread needs both planes of its chunk (threads < CHP do the work)
     auto load_tile = [&](int tl) {
-        const int r = tl * 16 + sjj;
+        const int r = gtile(tl) * 16 + sjj;
         if constexpr (DROP) {
             st = zero8; st2 = zero8;
             if (tid < CHP && r < R) {
@@ -413,7 +431,7 @@ __global__ void __launch_bounds__(4 * H) xproj_sp_kernel(XprojArgsS a, int tiles
     auto store_tile = [&](int tl, int buf) {
         if constexpr (DROP) {
             if (tid < CHP) {
-                const int r = tl * 16 + sjj;
+                const int r = gtile(tl) * 16 + sjj;
                 bf16x8 oh, ol;
                 const uint32_t idx = (uint32_t)((size_t)r * H + sc8);     // element index = tile-blocked row * H + unit (host replica: shm_dropout_keep_mask_tiled)
 #pragma unroll
@@ -455,7 +473,7 @@ __global__ void __launch_bounds__(4 * H) xproj_sp_kernel(XprojArgsS a, int tiles
                 acc[g] = mfma_bf16_16x16x32(whi[g][s], bl, acc[g]);
             }
         }
-        const int r = tl * 16 + j;                        // accumulator column j = tile row j
+        const int r = gtile(tl) * 16 + j;                 // accumulator column j = tile row j
         if (r < R) {
             f32x4* dst = reinterpret_cast<f32x4*>(a.out) + ((size_t)(r >> 2) * NW + ht) * 64 + q * 16 + (r & 3);
 #pragma unroll
@@ -485,7 +503,8 @@ __global__ void __launch_bounds__(4 * H) dx_sp_kernel(DxArgsS a, int tiles_per_w
     }
     const uint32_t thr = drop_threshold(a.drop_p);
     const float dscale = DROP ? 1.0f / (1.0f - a.drop_p) : 1.0f;
-    const int R = a.rows, n_tiles = (R + 15) / 16;
+    const int R = a.rows, n_tiles = a.cpt > 0 ? a.n_chunk_tiles : (R + 15) / 16;
+    auto gtile = [&](int k) { return a.cpt > 0 ? (k / a.cpt) * a.seq_tiles + a.tile_off + (k % a.cpt) : k; };   // see xproj_sp_kernel
     const int t0 = blockIdx.x * tiles_per_wg, t1 = min(n_tiles, t0 + tiles_per_wg);
     constexpr int CHP = 16 * 4 * H / 8, CPT = 2 * CHP / NTHR;            // chunks per plane; = 4 chunks per thread
     static_assert(CPT * NTHR == 2 * CHP && CHP % NTHR == 0, "whole chunks per thread, a thread's chunks stay in one plane");
@@ -495,7 +514,7 @@ __global__ void __launch_bounds__(4 * H) dx_sp_kernel(DxArgsS a, int tiles_per_w
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
             const int e = tid + i * NTHR, pl = e >= CHP ? 1 : 0, cch = e - pl * CHP;
-            const int jj = cch / (4 * H / 8), c8 = (cch - jj * (4 * H / 8)) * 8, r = tl * 16 + jj;
+            const int jj = cch / (4 * H / 8), c8 = (cch - jj * (4 * H / 8)) * 8, r = gtile(tl) * 16 + jj;
             st[i] = r < R ? *reinterpret_cast<const bf16x8*>((pl ? a.dpre_lo : a.dpre_hi) + (size_t)r * 4 * H + c8) : zero8;
         }
     };
@@ -526,12 +545,13 @@ __global__ void __launch_bounds__(4 * H) dx_sp_kernel(DxArgsS a, int tiles_per_w
             acc1 = mfma_bf16_16x16x32(whi[s + 1], l1, acc1);
         }
         f32x4 d = acc0 + acc1;
+        const int gt = gtile(tl);
         if (DROP) {
-            const uint32_t base = (uint32_t)(((size_t)tl * 16 + j) * H + ht * 16 + q * 4);
+            const uint32_t base = (uint32_t)(((size_t)gt * 16 + j) * H + ht * 16 + q * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) d[e] = drop_hash(a.drop_seed, a.drop_stack, base + e) >= thr ? d[e] * dscale : 0.f;
         }
-        *reinterpret_cast<f32x4*>(a.dx + (((size_t)tl * NW + ht) * 64 + lane) * 4) = d;
+        *reinterpret_cast<f32x4*>(a.dx + (((size_t)gt * NW + ht) * 64 + lane) * 4) = d;
         if (tl + 1 < t1) store_tile(cur ^ 1);
         __syncthreads();
     }
@@ -573,7 +593,7 @@ inline int tiles_per_wg_for(int n_tiles) { return n_tiles >= 2048 ? 8 : 1; }
 
 template <int H>
 int launch_xproj_h(const XprojArgsS& a, hipStream_t s) {
-    const int n_tiles = ceil_div(a.rows, 16), tpw = tiles_per_wg_for(n_tiles), grid = ceil_div(n_tiles, tpw);
+    const int n_tiles = a.cpt > 0 ? a.n_chunk_tiles : ceil_div(a.rows, 16), tpw = tiles_per_wg_for(n_tiles), grid = ceil_div(n_tiles, tpw);
     if (a.drop_p > 0.f) SHM_LAUNCH((xproj_sp_kernel<H, true>), dim3(grid), dim3(4 * H), 0, s, a, tpw);
     else SHM_LAUNCH((xproj_sp_kernel<H, false>), dim3(grid), dim3(4 * H), 0, s, a, tpw);
     SHM_LAUNCH_CHECK();
@@ -582,7 +602,7 @@ int launch_xproj_h(const XprojArgsS& a, hipStream_t s) {
 
 template <int H>
 int launch_dx_h(const DxArgsS& a, hipStream_t s) {
-    const int n_tiles = ceil_div(a.rows, 16), tpw = tiles_per_wg_for(n_tiles), grid = ceil_div(n_tiles, tpw);
+    const int n_tiles = a.cpt > 0 ? a.n_chunk_tiles : ceil_div(a.rows, 16), tpw = tiles_per_wg_for(n_tiles), grid = ceil_div(n_tiles, tpw);
     const size_t lds = sizeof(bf16_t) * 2 * 2 * 4 * 16 * lds_row_stride(H);
     if (a.drop_p > 0.f) {
         static bool attr = false;
@@ -607,16 +627,22 @@ int launch_dx_h(const DxArgsS& a, hipStream_t s) {
         default: set_error(what ": hidden_dim %d unsupported (32, 64, 128)", H); return SHM_EINVAL;     \
     }
 
-int launch_lstm_fwd_sp(int H, const LstmFwdArgsS& a, hipStream_t s) {
-    SHM_REQUIRE(a.B > 0 && a.T > 0, SHM_EINVAL, "lstm_fwd_sp: empty shape");
+int launch_lstm_fwd_sp(int H, const LstmFwdArgsS& a0, hipStream_t s) {
+    LstmFwdArgsS a = a0;
+    if (a.t1 == 0) { a.t0 = 0; a.t1 = a.T; }                // whole window
+    SHM_REQUIRE(a.B > 0 && a.T > 0 && a.t0 >= 0 && a.t0 < a.t1 && a.t1 <= a.T, SHM_EINVAL, "lstm_fwd_sp: empty shape or bad chunk [%d, %d) of %d", a.t0, a.t1, a.T);
+    SHM_REQUIRE((a.t0 == 0 && a.t1 == a.T) || a.c_state, SHM_EINVAL, "lstm_fwd_sp: a time chunk needs the cell-state buffer");
     SHM_REQUIRE(a.Wh_hi && a.Wh_lo && a.h_hi && a.h_lo, SHM_EINVAL, "lstm_fwd_sp: packed weights or h planes missing");
     SHM_REQUIRE((a.rec4 != nullptr) == (a.rec2 != nullptr), SHM_EINVAL, "lstm_fwd_sp: both record planes or neither");
     if (a.mode == 2) SHM_REQUIRE(a.x && a.Wx_hi && a.Wx_lo && a.bias && a.In >= 1 && a.In <= 16, SHM_EINVAL, "lstm_fwd_sp: mode 2 needs x, W_ih, bias and In <= 16 (got %d)", a.In);
     else SHM_REQUIRE(a.xproj && (a.mode == 0 || a.mode == 1), SHM_EINVAL, "lstm_fwd_sp: modes 0/1 need the projected input");
     SHM_DISPATCH_H(launch_fwd_h, "lstm_fwd_sp")
 }
-int launch_lstm_bwd_sp(int H, const LstmBwdArgsS& a, hipStream_t s) {
-    SHM_REQUIRE(a.B > 0 && a.T > 0, SHM_EINVAL, "lstm_bwd_sp: empty shape");
+int launch_lstm_bwd_sp(int H, const LstmBwdArgsS& a0, hipStream_t s) {
+    LstmBwdArgsS a = a0;
+    if (a.t1 == 0) { a.t0 = 0; a.t1 = a.T; }
+    SHM_REQUIRE(a.B > 0 && a.T > 0 && a.t0 >= 0 && a.t0 < a.t1 && a.t1 <= a.T, SHM_EINVAL, "lstm_bwd_sp: empty shape or bad chunk [%d, %d) of %d", a.t0, a.t1, a.T);
+    SHM_REQUIRE((a.t0 == 0 && a.t1 == a.T) || a.state, SHM_EINVAL, "lstm_bwd_sp: a time chunk needs the (dc, dh) state buffer");
     SHM_REQUIRE(a.rec4 && a.rec2 && a.dpre_hi && a.dpre_lo && a.WhT_hi && a.WhT_lo, SHM_ESTATE, "lstm_bwd_sp: no saved forward state / dpre planes / weights");
     SHM_REQUIRE(!a.dy || (a.Wout && a.Dy > 0 && a.Dy <= 64), SHM_EINVAL, "lstm_bwd_sp: bad output-layer gradient");
     SHM_DISPATCH_H(launch_bwd_h, "lstm_bwd_sp")

@@ -120,10 +120,12 @@ class VAEEngine:
         """mu, logvar of temporal_vae.py:51-58; the decoder does not run."""
         x = self._check_x(x)
         B, T, _ = x.shape
-        pl = self.plan(B, T, False)
-        self._pack(pl)
         mu = torch.empty(B, self.cfg.latent_dim, dtype=torch.float32, device=x.device)
         lv = torch.empty_like(mu)
+        if B == 0:
+            return mu, lv
+        pl = self.plan(B, T, False)
+        self._pack(pl)
         check(lib.shm_vae_encode(pl.handle, _ptr(x), _ptr(mu), _ptr(lv), int(bool(train_mode)), C.c_uint64(int(drop_seed) & (2 ** 64 - 1)),
                                  _ptr(pl.ws), _stream()), "shm_vae_encode")
         self.last_plan = pl
@@ -137,9 +139,11 @@ class VAEEngine:
             raise RuntimeError(f"expected z of shape [B, {self.cfg.latent_dim}], got {tuple(z.shape)}")
         z = z.contiguous().float()
         B = z.size(0)
+        recon = torch.empty(B, int(seq_len), self.cfg.input_dim, dtype=torch.float32, device=z.device)
+        if B == 0:
+            return recon
         pl = self.plan(B, int(seq_len), False)
         self._pack(pl)
-        recon = torch.empty(B, int(seq_len), self.cfg.input_dim, dtype=torch.float32, device=z.device)
         check(lib.shm_vae_decode(pl.handle, _ptr(z), _ptr(recon), int(bool(train_mode)), C.c_uint64(int(drop_seed) & (2 ** 64 - 1)),
                                  _ptr(pl.ws), _stream()), "shm_vae_decode")
         self.last_plan = pl
@@ -149,6 +153,10 @@ class VAEEngine:
         """eps: injected noise [B, Z]; or None with eps_stream = (seed, offset): drawn on the device inside the head kernel."""
         x = self._check_x(x)
         B, T, D = x.shape
+        if B == 0:      # an empty batch (the reference's modules return empty tensors): nothing to launch
+            Z = self.cfg.latent_dim
+            e = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=x.device)
+            return (e(0, T, D) if want_recon else None), e(0, Z), e(0, Z), (e(0) if want_score else None), None, x
         if eps is not None:
             eps = eps.contiguous().float()
             if tuple(eps.shape) != (B, self.cfg.latent_dim):

@@ -97,3 +97,31 @@ def test_no_aten_kernel_on_the_fused_step():
     if not names:
         pytest.skip("torch.profiler returned no device activity on this box")
     assert not foreign, foreign
+
+
+@pytest.mark.parametrize("prec", ["split", "bf16"])
+def test_empty_batch_and_long_sequence(prec):
+    """Edge cases of the module API: an empty batch returns empty tensors (as the reference's nn modules do), and a sequence four times
+    the north-star length (T = 1024: the persistent loops' counted waits, prefetch rings and 32-bit offsets) still matches the fp64
+    oracle — recon / mu / logvar at the precision's forward bars."""
+    from oracle.vae_oracle import VAEOracle
+    g = load_golden("vae_fwd_ns_h128")
+    p = split_prefix(g, "p.")
+    m = build_module(g["cfg"], p, precision=prec).eval()
+    with torch.no_grad():
+        r0, m0, l0 = m(torch.zeros(0, 256, 4).cuda())
+        assert r0.shape == (0, 256, 4) and m0.shape == (0, 16) and l0.shape == (0, 16)
+        assert m.score(torch.zeros(0, 256, 4).cuda()).shape == (0,) and m.encode(torch.zeros(0, 64, 4).cuda())[0].shape == (0, 16)
+        assert m.decode(torch.zeros(0, 16).cuda(), 32).shape == (0, 32, 4)
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((6, 1024, 4)).astype(np.float32)
+    eps = rng.standard_normal((6, 16)).astype(np.float32)
+    recon, mu, lv, score = VAEOracle(p, 2, True).forward(x, eps)
+    with torch.no_grad(), inject_eps([torch.tensor(eps)]):
+        r2, m2, l2 = m(torch.tensor(x).cuda())
+    d = dict(recon=maxdiff(r2, recon), mu=maxdiff(m2, mu), logvar=maxdiff(l2, lv))
+    print("T=1024", prec, d)
+    if prec == "split":
+        assert max(d.values()) < 1e-4, d
+    else:
+        assert d["recon"] < 2e-3 and d["mu"] < 1e-2 and d["logvar"] < 1e-2, d

@@ -267,3 +267,34 @@ def test_full_size_properties(prec):
     assert torch.isfinite(r1).all()
     ref_score = ((x - r1) ** 2).mean(dim=(1, 2))
     assert maxdiff(sc, ref_score.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("nc", [2, 4])
+def test_split_time_chunked_layer_pipeline_equals_one_launch_per_layer(nc, monkeypatch):
+    """SHM_SP_CHUNKS (api.hip: sp_chunks): the split path's layers run as a launch-level pipeline over time chunks, (c) / (dc, dh) carried
+    through the workspace between chunk launches.  Same arithmetic in the same order per step: the forward is bit-identical; in the
+    backward only sum_t dpre is accumulated chunk by chunk (fp32 re-association), so gradients agree to ~1e-6 of their max.  Dropout
+    on: the masks are hashed from (seed, stack, row), not from the launch, and must not move."""
+    from Scripts.Models.temporal_vae import TemporalVAE
+    from shm_hip.trainer import VAETrainer
+    B, T = 37, 64
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(B, T, 4, generator=gen).cuda()
+    eps = torch.randn(B, 16, generator=gen).cuda()
+    out = {}
+    for chunks in (1, nc):
+        monkeypatch.setenv("SHM_SP_CHUNKS", str(chunks))
+        torch.manual_seed(3)
+        m = TemporalVAE(4, 16, 128, 2, 0.3, precision="split").cuda().train()
+        tr = VAETrainer(m, lr=1e-3, weight_decay=1e-5, max_norm=2.0)
+        stats = tr.step(x, 0.5, eps=eps, drop_seed=77).cpu().numpy()
+        tr.check(stats)
+        m.eval()
+        with torch.no_grad(), inject_eps([eps.cpu()]):
+            rec, mu, lv = m(x)
+        out[chunks] = (stats, tr.grads.clone(), rec, mu, lv)
+    a, b = out[1], out[nc]
+    assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+    assert abs(a[0][0] - b[0][0]) <= 1e-6 * max(1.0, abs(a[0][0]))
+    gmax = float(a[1].abs().max())
+    assert float((a[1] - b[1]).abs().max()) < 2e-6 * gmax
