@@ -115,7 +115,7 @@ extern "C" int shm_cnn_plan_create(const shm_cnn_config* cfg, int32_t B, int32_t
         p->k1 = take(4 * C2); p->k2 = take(4 * C2);
         p->wpart = take(4 * Bz * (C2 * C1 * 9 + C2));
         size_t gp = gemm_tn_partial_elems(B, FC1, p->F);
-        const size_t gp2 = gemm_tn_partial_elems(B, (int)NC, FC1);
+        const size_t gp2 = cnn_dense_out_bwd_partial_elems(B, FC1, (int)NC);
         if (gp2 > gp) gp = gp2;
         p->gemm_partial_elems = gp;
         p->gemm_partial = take(4 * (gp ? gp : 1));
@@ -216,57 +216,62 @@ extern "C" int shm_cnn_backward(shm_cnn_plan* p, const float* params, const floa
         g.partial = at<float>(ws, part_off); g.partial_elems = p->gemm_partial_elems;
         return launch_gemm_tn_f32(g, s, &rjobs);
     };
-    // fc2: dW = dl^T a1, db = colsum(dl), da1 = dl W2 with the dropout and ReLU masks of fc1 re-applied -> dz1
-    { KernelTimer kt("cnn.fc2_dw", (hipStream_t)stream);
-    if ((rc = gemm(dl, NC, at<float>(ws, p->a1), FC1, grads + p->f2w, p->gemm_partial))) return rc;
+    // fc2, one launch: dW = dl^T a1 and db = colsum(dl) as per-16-window partials, da1 = dl W2 with the dropout and ReLU masks of fc1
+    // re-applied -> dz1
+    { KernelTimer kt("cnn.fc2_bwd", (hipStream_t)stream);
+    if ((rc = cnn_dense_out_bwd(B, FC1, NC, dl, params + p->f2w, at<float>(ws, p->z1), at<float>(ws, p->a1), at<float>(ws, p->dz1),
+                                at<float>(ws, p->gemm_partial), grads + p->f2w, grads + p->f2b, p->drop_p_used, p->drop_seed, s, rjobs))) return rc;
     }
-    { KernelTimer kt("cnn.fc2_db", (hipStream_t)stream);
-    if ((rc = launch_colsum(dl, NC, B, NC, grads + p->f2b, nullptr, at<float>(ws, p->colsum_scratch), s, &rjobs))) return rc;
-    }
-    { KernelTimer kt("cnn.fc2_dx", (hipStream_t)stream);
-    if ((rc = cnn_linear_bwd_dx(B, FC1, NC, dl, params + p->f2w, at<float>(ws, p->z1), at<float>(ws, p->dz1), p->drop_p_used, p->drop_seed, s))) return rc;
-    }
-    // fc1
+    // fc1: dW = dz1^T p2 and db = colsum(dz1) as one direct MFMA product (split-K GEMM + column sum when the layer does not tile)
     const float* dz1 = at<float>(ws, p->dz1);
-    { KernelTimer kt("cnn.fc1_dw", (hipStream_t)stream);
-    if ((rc = gemm(dz1, FC1, at<float>(ws, p->p2), F, grads + p->f1w, p->gemm_partial2))) return rc;
-    }
-    { KernelTimer kt("cnn.fc1_db", (hipStream_t)stream);
-    if ((rc = launch_colsum(dz1, FC1, B, FC1, grads + p->f1b, nullptr, at<float>(ws, p->colsum_scratch2), s, &rjobs))) return rc;
+    if (cnn_dense_dw_direct_ok(F, FC1)) {
+        KernelTimer kt("cnn.fc1_dw", (hipStream_t)stream);
+        if ((rc = cnn_dense_dw(B, F, FC1, dz1, at<float>(ws, p->p2), grads + p->f1w, grads + p->f1b, s))) return rc;
+    } else {
+        { KernelTimer kt("cnn.fc1_dw", (hipStream_t)stream);
+        if ((rc = gemm(dz1, FC1, at<float>(ws, p->p2), F, grads + p->f1w, p->gemm_partial2))) return rc;
+        }
+        KernelTimer kt("cnn.fc1_db", (hipStream_t)stream);
+        if ((rc = launch_colsum(dz1, FC1, B, FC1, grads + p->f1b, nullptr, at<float>(ws, p->colsum_scratch2), s, &rjobs))) return rc;
     }
     { KernelTimer kt("cnn.fc1_dx", (hipStream_t)stream);
     if ((rc = cnn_linear_bwd_dx(B, F, FC1, dz1, params + p->f1w, nullptr, at<float>(ws, p->dflat), 0.f, 0, s))) return rc;
     }
-    // block 2
+    // block 2.  The BatchNorm backward is its statistics pass only: the per-position gradient dy2 is formed inside the two conv gradient
+    // kernels (never written) whenever the matrix-pipe weight gradient can run; otherwise the apply launch writes it as before.
     float* wpart = at<float>(ws, p->wpart);
+    const BnGrad g2{at<float>(ws, p->y2), at<float>(ws, p->dflat), at<unsigned char>(ws, p->i2), at<float>(ws, p->mean2), at<float>(ws, p->rstd2),
+                    params + p->g2, at<float>(ws, p->k1), at<float>(ws, p->k2)};
+    const bool fuse2 = cnn_conv_bwd_weight_fusable(2, p->H1, p->W1, g2.y);
     { KernelTimer kt("cnn.bn2_bwd", (hipStream_t)stream);
-    if ((rc = cnn_bn_bwd(B, C2, p->H1, p->W1, at<float>(ws, p->dflat), at<unsigned char>(ws, p->i2), at<float>(ws, p->y2), at<float>(ws, p->mean2),
-                         at<float>(ws, p->rstd2), params + p->g2, at<float>(ws, p->part2), at<float>(ws, p->k1), at<float>(ws, p->k2),
-                         grads + p->g2, grads + p->b2, at<float>(ws, p->dy2), s))) return rc;
+    if ((rc = cnn_bn_bwd_stats(B, C2, p->H1, p->W1, g2.dp, g2.idx, g2.y, g2.mean, g2.rstd, at<float>(ws, p->part2), at<float>(ws, p->k1), at<float>(ws, p->k2),
+                               grads + p->g2, grads + p->b2, s))) return rc;
+    if (!fuse2 && (rc = cnn_bn_bwd_apply(B, C2, p->H1, p->W1, g2, at<float>(ws, p->dy2), s))) return rc;
     }
     { KernelTimer kt("cnn.conv2_dw", (hipStream_t)stream);
-    if ((rc = cnn_conv_bwd_weight(2, B, p->H1, p->W1, at<float>(ws, p->dy2), at<float>(ws, p->p1), wpart, s))) return rc;
+    if ((rc = cnn_conv_bwd_weight(2, B, p->H1, p->W1, at<float>(ws, p->dy2), fuse2 ? &g2 : nullptr, at<float>(ws, p->p1), wpart, s))) return rc;
     }
     {
-        // partial rows are [C2*C1*9 weights | C2 biases]; weights and bias are adjacent in neither buffer, so reduce into a
-        // scratch row (the tail of wpart's last row is free: reuse colsum scratch sized >= that) then scatter
-        // straight into the two gradient tensors: the weight block and the bias block of every partial row, each with the row stride
+        // partial rows are [C2*C1*9 weights | C2 biases]: the weight block and the bias block of every partial row, each with the row stride
         const size_t nw = (size_t)C2 * C1 * 9, n = nw + C2;
         if ((rc = reduce_jobs_add(rjobs, wpart, B, nw, n, grads + p->c2w, nullptr))) return rc;
         if ((rc = reduce_jobs_add(rjobs, wpart + nw, B, (size_t)C2, n, grads + p->c2b, nullptr))) return rc;
     }
     { KernelTimer kt("cnn.conv2_dx", (hipStream_t)stream);
-    if ((rc = cnn_conv_bwd_data2(B, p->H1, p->W1, at<float>(ws, p->dy2), params + p->c2w, at<float>(ws, p->dp1), s))) return rc;
+    if ((rc = cnn_conv_bwd_data2(B, p->H1, p->W1, at<float>(ws, p->dy2), fuse2 ? &g2 : nullptr, params + p->c2w, at<float>(ws, p->dp1), s))) return rc;
     }
-    // block 1
+    // block 1 (k1 / k2 of block 2 are consumed: the stream orders the reuse)
+    const BnGrad g1{at<float>(ws, p->y1), at<float>(ws, p->dp1), at<unsigned char>(ws, p->i1), at<float>(ws, p->mean1), at<float>(ws, p->rstd1),
+                    params + p->g1, at<float>(ws, p->k1), at<float>(ws, p->k2)};
+    const bool fuse1 = cnn_conv_bwd_weight_fusable(1, p->H0, p->W0, g1.y);
     { KernelTimer kt("cnn.bn1_bwd", (hipStream_t)stream);
-    if ((rc = cnn_bn_bwd(B, C1, p->H0, p->W0, at<float>(ws, p->dp1), at<unsigned char>(ws, p->i1), at<float>(ws, p->y1), at<float>(ws, p->mean1),
-                         at<float>(ws, p->rstd1), params + p->g1, at<float>(ws, p->part1), at<float>(ws, p->k1), at<float>(ws, p->k2),
-                         grads + p->g1, grads + p->b1, at<float>(ws, p->dy1), s))) return rc;
+    if ((rc = cnn_bn_bwd_stats(B, C1, p->H0, p->W0, g1.dp, g1.idx, g1.y, g1.mean, g1.rstd, at<float>(ws, p->part1), at<float>(ws, p->k1), at<float>(ws, p->k2),
+                               grads + p->g1, grads + p->b1, s))) return rc;
+    if (!fuse1 && (rc = cnn_bn_bwd_apply(B, C1, p->H0, p->W0, g1, at<float>(ws, p->dy1), s))) return rc;
     }
     float* wpart1 = at<float>(ws, p->wpart1);
     { KernelTimer kt("cnn.conv1_dw", (hipStream_t)stream);
-    if ((rc = cnn_conv_bwd_weight(1, B, p->H0, p->W0, at<float>(ws, p->dy1), x, wpart1, s))) return rc;
+    if ((rc = cnn_conv_bwd_weight(1, B, p->H0, p->W0, at<float>(ws, p->dy1), fuse1 ? &g1 : nullptr, x, wpart1, s))) return rc;
     }
     {
         const size_t nw = (size_t)C1 * 2 * 9, n = nw + C1;

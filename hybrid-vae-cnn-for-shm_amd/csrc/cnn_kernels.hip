@@ -422,6 +422,126 @@ __global__ void __launch_bounds__(256) linear_bwd_dx_mfma_kernel(int B, int F, i
     }
 }
 
+// ------------------------------------------------------------------------------------------------ dense head, backward
+// Output layer, everything in one launch (was: split-K GEMM + column sum + data gradient = three launches and 30 us for ~0.3 MFLOP):
+//   dz1[b][f] = relu'(z1) * dropmask * sum_o dl[b][o] W2[o][f]                 (the hand-off into fc1's backward)
+//   part[g][o][f] = sum_{b in group g} dl[b][o] a1[b][f],  part[g][NC*F1 + o] = sum_{b in g} dl[b][o]
+// grid = ceil(B / 16), block = 2 * F1 threads (F1 = hidden width, <= 256): thread (half, f) walks 8 of the group's 16 windows; the two
+// halves are added in a fixed order.  The per-group partials go through the backward pass' one reduce launch.
+template <int NCMAX>
+__global__ void __launch_bounds__(512) dense_out_bwd_kernel(int B, int F1, int NC, const float* __restrict__ dl, const float* __restrict__ W2,
+                                                            const float* __restrict__ z1, const float* __restrict__ a1, float* __restrict__ dz1,
+                                                            float* __restrict__ part, float drop_p, unsigned long long drop_seed) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // [F1][NCMAX] partials of the upper half | [16][NCMAX] dl of the group
+    float* dls = sm + (size_t)F1 * NCMAX;
+    const int g = blockIdx.x, tid = threadIdx.x, f = tid % F1, half = tid / F1, b0 = g * 16;
+    for (int e = tid; e < 16 * NCMAX; e += blockDim.x) {
+        const int r = e / NCMAX, o = e - r * NCMAX;
+        dls[e] = (b0 + r < B && o < NC) ? dl[(size_t)(b0 + r) * NC + o] : 0.f;
+    }
+    float w2[NCMAX], acc[NCMAX];
+#pragma unroll
+    for (int o = 0; o < NCMAX; ++o) { w2[o] = o < NC ? W2[(size_t)o * F1 + f] : 0.f; acc[o] = 0.f; }
+    __syncthreads();
+    const uint32_t thr = drop_threshold(drop_p);
+    const float dscale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = half * 8 + i, b = b0 + r;
+        if (b < B) {
+            const size_t e = (size_t)b * F1 + f;
+            const float av = a1[e], zv = z1[e];
+            float d = 0.f;
+#pragma unroll
+            for (int o = 0; o < NCMAX; ++o) { d = fmaf(dls[r * NCMAX + o], w2[o], d); acc[o] = fmaf(dls[r * NCMAX + o], av, acc[o]); }
+            if (drop_p > 0.f) d = drop_hash(drop_seed, 2u, (uint32_t)e) >= thr ? d * dscale : 0.f;
+            dz1[e] = zv > 0.f ? d : 0.f;
+        }
+    }
+    if (half == 1) {
+#pragma unroll
+        for (int o = 0; o < NCMAX; ++o) sm[f * NCMAX + o] = acc[o];
+    }
+    __syncthreads();
+    float* out = part + (size_t)g * ((size_t)NC * F1 + NC);
+    if (half == 0) {
+#pragma unroll
+        for (int o = 0; o < NCMAX; ++o)
+            if (o < NC) out[(size_t)o * F1 + f] = acc[o] + sm[f * NCMAX + o];
+    }
+    if (tid < NC) {
+        float v = 0.f;
+        for (int r = 0; r < 16; ++r) v += dls[r * NCMAX + tid];
+        out[(size_t)NC * F1 + tid] = v;
+    }
+}
+
+// Hidden layer's weight gradient as ONE exact-fp32 MFMA product without split-K partials: dW[o][f] = sum_b dz[b][o] in[b][f], M = O (all
+// MT = O / 16 tiles in every wave), N = 16 columns f per workgroup, K = B dealt over the 8 waves in blocks of four windows; both
+// operands are read straight from global memory (lane (q, j): window 4 s + q, 16 consecutive o / f — 64-byte segments; dz is L2
+// resident, `in` is read exactly once by the whole grid), four k-blocks in flight per wave.  The wave accumulators are added in wave
+// order through LDS.  Workgroup 0 also leaves the bias gradient (column sums of dz) out of its A operands.  (Was: a 256-way split-K
+// GEMM + its share of the reduce launch + a column-sum launch: 26 us.)   Requires O % 16 == 0, F % 16 == 0.
+template <int MT>
+__global__ void __launch_bounds__(512) dense_dw_mfma_kernel(int B, int F, const float* __restrict__ dz, const float* __restrict__ in,
+                                                            float* __restrict__ dW, float* __restrict__ db) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // [8 waves][MT][256] accumulators | [8][MT * 16] row sums
+    constexpr int O = MT * 16, NWV = 8, PF = 4;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15, f0 = blockIdx.x * 16;
+    const int nks = (B + 3) / 4;                                      // k-blocks of four windows; wave w takes w, w + 8, ...
+    f32x4 acc[MT];
+    float bsum[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) { acc[m] = f32x4{0.f, 0.f, 0.f, 0.f}; bsum[m] = 0.f; }
+    float av[PF][MT], bv[PF];
+    auto fetch = [&](int u, int ks) {
+        const int b = 4 * ks + q;
+        const bool ok = ks < nks && b < B;
+        const int bc = ok ? b : 0;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) { const float v = dz[(size_t)bc * O + m * 16 + j]; av[u][m] = ok ? v : 0.f; }
+        const float v = in[(size_t)bc * F + f0 + j];
+        bv[u] = ok ? v : 0.f;
+    };
+#pragma unroll
+    for (int u = 0; u < PF; ++u) fetch(u, wave + u * NWV);
+    for (int ks0 = wave; ks0 < nks; ks0 += PF * NWV) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int ks = ks0 + u * NWV;
+            if (ks < nks) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) { acc[m] = mfma_f32_16x16x4(av[u][m], bv[u], acc[m]); bsum[m] += av[u][m]; }
+            }
+            fetch(u, ks + PF * NWV);
+        }
+    }
+    float* redb = sm + (size_t)NWV * MT * 256;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        *reinterpret_cast<f32x4*>(sm + ((size_t)(wave * MT + m) * 64 + lane) * 4) = acc[m];
+        float v = bsum[m];
+        v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+        if (q == 0) redb[wave * O + m * 16 + j] = v;
+    }
+    __syncthreads();
+    for (int e = tid; e < MT * 256; e += 512) {
+        const int m = e >> 8, l = (e & 255) >> 2, r = e & 3;         // accumulator (q, j), r  <->  row 4 q + r (o), column j (f)
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) v += sm[(size_t)(w * MT + m) * 256 + (e & 255)];
+        dW[(size_t)(m * 16 + 4 * (l >> 4) + r) * F + f0 + (l & 15)] = v;
+    }
+    if (blockIdx.x == 0 && db) {
+        for (int e = tid; e < O; e += 512) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWV; ++w) v += redb[w * O + e];
+            db[e] = v;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ cross-entropy
 // one block: loss = mean_b -log softmax(logits)[y_b]; dlogits = (softmax - onehot) / B    (nn.CrossEntropyLoss())
 __global__ void __launch_bounds__(256) ce_loss_kernel(int B, int NC, const float* __restrict__ logits, const long long* __restrict__ labels,
@@ -539,16 +659,49 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(int C, int H, int W, 
     }
 }
 
+// The pool / ReLU / BatchNorm backward of one element, for the kernels that form dy on the fly instead of reading it:
+// dy = gamma rstd (da - k1 - xhat k2), xhat = (y - mean) rstd, da = the pooled gradient if this position was the cell's first maximum.
+__device__ __forceinline__ float bn_dy(const BnGrad& g, int c, float y, float da) {
+    const float rs = g.rstd[c];
+    return g.gamma[c] * rs * (da - g.k1[c] - (y - g.mean[c]) * rs * g.k2[c]);
+}
+
 // ------------------------------------------------------------------------------------------------ conv backward
 // data gradient: dx[ci][h][w] = sum_co sum_k dy[co][h+1-kh][w+1-kw] W[co][ci][kh][kw]      grid = B
-template <int CIN, int COUT>
-__global__ void __launch_bounds__(256) conv3x3_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
-                                                               int H, int W) {
+// FUSE: dy is not read but formed while staging, from the pooled gradient and the saved conv output (bn_dy above) — the separate
+// bn_bwd_apply launch and its dy tensor (written once, read by both conv gradients) are gone.
+template <int CIN, int COUT, bool FUSE>
+__global__ void __launch_bounds__(256) conv3x3_bwd_data_kernel(const float* __restrict__ dy, BnGrad bn, const float* __restrict__ w,
+                                                               float* __restrict__ dx, int H, int W) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int HW = H * W, b = blockIdx.x, tid = threadIdx.x;
     float* ds = sm;                          // [COUT][HW]
     float* ws = sm + COUT * HW;              // [(co*9+k)][CIN]
-    stage_elems<256>(COUT * HW, tid, [&](int e) { return dy[(size_t)b * COUT * HW + e]; }, [&](int e, float v) { ds[e] = v; });
+    if constexpr (FUSE) {
+        const int Hp = H / 2, Wp = W / 2, npc = Hp * Wp;
+        for (int e0 = tid; e0 < COUT * HW; e0 += 256 * 8) {
+            float yv[8], dv[8];
+            int kk[8], sel[8], cc[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = min(e0 + u * 256, COUT * HW - 1), co = e / HW, p = e - co * HW, h = p / W, ww = p - h * W, hp = h >> 1, wp = ww >> 1;
+                const bool in = hp < Hp && wp < Wp;
+                const size_t pe = ((size_t)b * COUT + co) * npc + (in ? hp * Wp + wp : 0);
+                yv[u] = bn.y[(size_t)b * COUT * HW + e];
+                kk[u] = in ? (int)bn.idx[pe] : -1;
+                dv[u] = bn.dp[pe];
+                sel[u] = (h & 1) * 2 + (ww & 1);
+                cc[u] = co;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * 256;
+                if (e < COUT * HW) ds[e] = bn_dy(bn, cc[u], yv[u], kk[u] == sel[u] ? dv[u] : 0.f);
+            }
+        }
+    } else {
+        stage_elems<256>(COUT * HW, tid, [&](int e) { return dy[(size_t)b * COUT * HW + e]; }, [&](int e, float v) { ds[e] = v; });
+    }
     stage_elems<256>(COUT * CIN * 9, tid, [&](int e) { return w[e]; }, [&](int e, float v) {   // w[co][ci][k] -> ws[(co*9+k)*CIN + ci]
         const int co = e / (CIN * 9), r = e - co * CIN * 9, ci = r / 9, k = r - ci * 9;
         ws[(co * 9 + k) * CIN + ci] = v;
@@ -655,17 +808,41 @@ __global__ void __launch_bounds__(256) conv3x3_bwd_weight_kernel(const float* __
 // (conv1: 1 x 2) they split the positions and their accumulators are added in wave order.  The bias gradient (row sums of dy) falls
 // out of the A fragments: every lane adds its four values per k-block, the four lane quarters are combined by shuffles.
 // Requires H * W % 4 == 0 (16-byte reads of dy rows).
-template <int CIN, int COUT>
-__global__ void __launch_bounds__(512) conv3x3_bwd_weight_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+// FUSE: the A operand dy is formed on the fly (bn_dy): a lane reads 16 bytes of the saved conv output y, looks its four positions' pooled
+// cells up in an LDS table (pref: cell << 2 | position within the 2x2 cell) and the cells' (gradient, argmax) records in an LDS copy of
+// the window's pooled gradient — the bn_bwd_apply launch and the dy tensor are gone.
+template <int CIN, int COUT, bool FUSE>
+__global__ void __launch_bounds__(512) conv3x3_bwd_weight_mfma_kernel(const float* __restrict__ dy, BnGrad bn, const float* __restrict__ x,
                                                                       float* __restrict__ part, int H, int W) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int NCOL = CIN * 9, MT = COUT / 16, NT = (NCOL + 15) / 16, NWV = 8, NW_ = COUT * NCOL, PF = 4;
     constexpr bool TILE_PAR = MT * NT >= NWV;
     const int HW = H * W, KP = (HW + 15) & ~15, NKB = KP / 16, WP = W + 2, XP = (H + 2) * WP, XPP = (CIN * XP + 3) & ~3;
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
+    const int Hp = H / 2, Wp = W / 2, npc = Hp * Wp, NPC1 = npc + 1;
     float* xs = sm;                                           // [CIN][H + 2][W + 2], zero halo
     int* posoff = reinterpret_cast<int*>(xs + XPP);           // [KP]: (h + 1) * WP + (w + 1) of position p
-    float* red = reinterpret_cast<float*>(posoff + KP);       // position-split only: [NWV][MT * NT][256] accumulators | [NWV][COUT] row sums
+    int* pref = posoff + KP;                                  // FUSE: [KP] pooled cell << 2 | (h & 1) * 2 + (w & 1); cell npc = "no cell"
+    f32x2* pc = reinterpret_cast<f32x2*>(pref + (FUSE ? KP : 0));   // FUSE: [COUT][npc + 1] (pooled gradient, argmax as int bits)
+    float* red = reinterpret_cast<float*>(pc + (FUSE ? (size_t)COUT * NPC1 : 0));   // position-split only: [NWV][MT * NT][256] accumulators | [NWV][COUT] row sums
+    if constexpr (FUSE) {
+        for (int p = tid; p < KP; p += 512) {
+            const int h = p / W, w2 = p - h * W, hp = h >> 1, wp = w2 >> 1;
+            pref[p] = ((p < HW && hp < Hp && wp < Wp) ? hp * Wp + wp : npc) << 2 | ((h & 1) * 2 + (w2 & 1));
+        }
+        for (int e0 = tid; e0 < COUT * NPC1; e0 += 512 * 4) {
+            float dv[4]; int kv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = min(e0 + u * 512, COUT * NPC1 - 1), co = e / NPC1, cell = e - co * NPC1;
+                const size_t pe = ((size_t)b * COUT + co) * npc + (cell < npc ? cell : 0);
+                dv[u] = bn.dp[pe]; kv[u] = cell < npc ? (int)bn.idx[pe] : 4;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (e0 + u * 512 < COUT * NPC1) pc[e0 + u * 512] = f32x2{dv[u], __int_as_float(kv[u])};
+        }
+    }
     // eight loads in flight per thread: issued one per trip, every global read would wait out its full latency before the next
     for (int e0 = tid; e0 < CIN * XP; e0 += 512 * 8) {
         float v[8];
@@ -689,21 +866,43 @@ __global__ void __launch_bounds__(512) conv3x3_bwd_weight_mfma_kernel(const floa
         boff = ci * XP + (tap / 3 - 1) * WP + (tap % 3 - 1);
         keep = ok ? 1.f : 0.f;
     };
-    auto a_load = [&](const float* arow, int kb) -> f32x4 {   // positions kb*16 + 4q .. +3 of this lane's dy row (zero past the window)
+    // this lane's dy rows are channels m * 16 + j: their BatchNorm-backward constants (FUSE)
+    float cm[MT], crs[MT], csc[MT], ck1[MT], ck2[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        if constexpr (FUSE) {
+            const int c = m * 16 + j;
+            cm[m] = bn.mean[c]; crs[m] = bn.rstd[c]; csc[m] = bn.gamma[c] * bn.rstd[c]; ck1[m] = bn.k1[c]; ck2[m] = bn.k2[c];
+        } else { cm[m] = crs[m] = csc[m] = ck1[m] = ck2[m] = 0.f; }
+    }
+    // positions kb*16 + 4q .. +3 of this lane's dy row of M-tile m (zero past the window); arow: the row in dy, or in y (FUSE)
+    auto a_load = [&](const float* arow, int kb, int m) -> f32x4 {
         const int kk = kb < NKB ? kb : NKB - 1, p = kk * 16 + 4 * q;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(arow + (p < HW ? p : 0));
+        f32x4 v = *reinterpret_cast<const f32x4*>(arow + (p < HW ? p : 0));
+        if constexpr (FUSE) {
+            const int4 pr = *reinterpret_cast<const int4*>(pref + kk * 16 + 4 * q);
+            const f32x2* pcr = pc + (size_t)(m * 16 + j) * NPC1;
+            const int prs[4] = {pr.x, pr.y, pr.z, pr.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const f32x2 rec = pcr[prs[e] >> 2];
+                const float da = __float_as_int(rec[1]) == (prs[e] & 3) ? rec[0] : 0.f;
+                v[e] = csc[m] * (da - ck1[m] - (v[e] - cm[m]) * crs[m] * ck2[m]);
+            }
+        }
         return p < HW ? v : zero4;
     };
+    const float* arows = FUSE ? bn.y + (size_t)b * COUT * HW : dyb;
     if constexpr (TILE_PAR) {
         constexpr int G = NWV / MT, NTW = (NT + G - 1) / G;
         const int mt = wave % MT, g = wave / MT, nt0 = (g * NT) / G, ntn = ((g + 1) * NT) / G - nt0;
         int boff[NTW]; float keep[NTW]; f32x4 acc[NTW];
 #pragma unroll
         for (int i = 0; i < NTW; ++i) { column(nt0 + (i < ntn ? i : 0), boff[i], keep[i]); acc[i] = zero4; }
-        const float* arow = dyb + (size_t)(mt * 16 + j) * HW;
+        const float* arow = arows + (size_t)(mt * 16 + j) * HW;
         f32x4 ar[PF];
 #pragma unroll
-        for (int u = 0; u < PF; ++u) ar[u] = a_load(arow, u);
+        for (int u = 0; u < PF; ++u) ar[u] = a_load(arow, u, mt);
         float bsum = 0.f;
         for (int kb0 = 0; kb0 < NKB; kb0 += PF) {
 #pragma unroll
@@ -724,7 +923,7 @@ __global__ void __launch_bounds__(512) conv3x3_bwd_weight_mfma_kernel(const floa
                             acc[i] = mfma_f32_16x16x4(a[3], xb[p3] * keep[i], acc[i]);
                         }
                 }
-                ar[u] = a_load(arow, kb + PF);
+                ar[u] = a_load(arow, kb + PF, mt);
             }
         }
 #pragma unroll
@@ -752,7 +951,7 @@ __global__ void __launch_bounds__(512) conv3x3_bwd_weight_mfma_kernel(const floa
 #pragma unroll
         for (int u = 0; u < PF; ++u)
 #pragma unroll
-            for (int m = 0; m < MT; ++m) ar[u][m] = a_load(dyb + (size_t)(m * 16 + j) * HW, wave + u * NWV);
+            for (int m = 0; m < MT; ++m) ar[u][m] = a_load(arows + (size_t)(m * 16 + j) * HW, wave + u * NWV, m);
         for (int kb0 = wave; kb0 < NKB; kb0 += PF * NWV) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
@@ -777,7 +976,7 @@ __global__ void __launch_bounds__(512) conv3x3_bwd_weight_mfma_kernel(const floa
                     }
                 }
 #pragma unroll
-                for (int m = 0; m < MT; ++m) ar[u][m] = a_load(dyb + (size_t)(m * 16 + j) * HW, kb + PF * NWV);
+                for (int m = 0; m < MT; ++m) ar[u][m] = a_load(arows + (size_t)(m * 16 + j) * HW, kb + PF * NWV, m);
             }
         }
         float* redb = red + (size_t)NWV * TILES * 256;          // [NWV][COUT]
@@ -887,6 +1086,35 @@ int cnn_linear_bwd_dx(int B, int F, int O, const float* dy, const float* Wt, con
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
+size_t cnn_dense_out_bwd_partial_elems(int B, int F1, int NC) { return (size_t)ceil_div(B, 16) * ((size_t)NC * F1 + NC); }
+int cnn_dense_out_bwd(int B, int F1, int NC, const float* dl, const float* W2, const float* z1, const float* a1, float* dz1, float* part,
+                      float* dW2, float* db2, float drop_p, uint64_t seed, hipStream_t s, ReduceJobs& jobs) {
+    SHM_REQUIRE(F1 >= 16 && F1 <= 256 && NC >= 1 && NC <= 16, SHM_EINVAL, "cnn dense_out_bwd: F1 %d / NC %d unsupported", F1, NC);
+    const int G = ceil_div(B, 16);
+    if (NC <= 4) {
+        const size_t lds = sizeof(float) * ((size_t)F1 * 4 + 16 * 4);
+        SHM_LAUNCH((dense_out_bwd_kernel<4>), dim3(G), dim3(2 * F1), lds, s, B, F1, NC, dl, W2, z1, a1, dz1, part, drop_p, (unsigned long long)seed);
+    } else {
+        const size_t lds = sizeof(float) * ((size_t)F1 * 16 + 16 * 16);
+        SHM_LAUNCH((dense_out_bwd_kernel<16>), dim3(G), dim3(2 * F1), lds, s, B, F1, NC, dl, W2, z1, a1, dz1, part, drop_p, (unsigned long long)seed);
+    }
+    SHM_LAUNCH_CHECK();
+    const size_t nw = (size_t)NC * F1, n = nw + NC;
+    int rc;
+    if ((rc = reduce_jobs_add(jobs, part, G, nw, n, dW2, nullptr))) return rc;
+    return reduce_jobs_add(jobs, part + nw, G, (size_t)NC, n, db2, nullptr);
+}
+bool cnn_dense_dw_direct_ok(int F, int O) { return O == 128 && F % 16 == 0 && !getenv("SHM_CNN_SPLITK_DENSE"); }
+int cnn_dense_dw(int B, int F, int O, const float* dz, const float* in, float* dW, float* db, hipStream_t s) {
+    SHM_REQUIRE(cnn_dense_dw_direct_ok(F, O), SHM_EINVAL, "cnn dense_dw: O %d / F %d unsupported", O, F);
+    constexpr int MT = 8;
+    const size_t lds = sizeof(float) * ((size_t)8 * MT * 256 + 8 * MT * 16);
+    int rc = opt_in_lds(dense_dw_mfma_kernel<MT>, lds);
+    if (rc) return rc;
+    SHM_LAUNCH((dense_dw_mfma_kernel<MT>), dim3(F / 16), dim3(512), lds, s, B, F, dz, in, dW, db);
+    SHM_LAUNCH_CHECK();
+    return SHM_OK;
+}
 int cnn_ce_loss(int B, int NC, const float* logits, const long long* labels, float* dlogits, float* loss, hipStream_t s) {
     SHM_LAUNCH(ce_loss_kernel, dim3(1), dim3(256), 0, s, B, NC, logits, labels, dlogits, loss);
     SHM_LAUNCH_CHECK();
@@ -903,37 +1131,67 @@ int cnn_build_input(int B, int TD, const float* z, const float* zhat, float* xin
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
-int cnn_bn_bwd(int B, int C, int H, int W, const float* dp, const unsigned char* idx, const float* y, const float* mean, const float* rstd,
-               const float* gamma, float* part, float* k1, float* k2, float* dgamma, float* dbeta, float* dy, hipStream_t s) {
+int cnn_bn_bwd_stats(int B, int C, int H, int W, const float* dp, const unsigned char* idx, const float* y, const float* mean, const float* rstd,
+                     float* part, float* k1, float* k2, float* dgamma, float* dbeta, hipStream_t s) {
     SHM_LAUNCH(bn_bwd_stats_kernel, dim3(B), dim3(256), 0, s, C, H, W, dp, idx, y, mean, rstd, part);
     SHM_LAUNCH_CHECK();
     SHM_LAUNCH(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, C, B, (long long)B * H * W, part, k1, k2, dgamma, dbeta);
     SHM_LAUNCH_CHECK();
-    SHM_LAUNCH(bn_bwd_apply_kernel, dim3(B), dim3(256), 0, s, C, H, W, dp, idx, y, mean, rstd, gamma, k1, k2, dy);
+    return SHM_OK;
+}
+int cnn_bn_bwd_apply(int B, int C, int H, int W, const BnGrad& g, float* dy, hipStream_t s) {
+    SHM_LAUNCH(bn_bwd_apply_kernel, dim3(B), dim3(256), 0, s, C, H, W, g.dp, g.idx, g.y, g.mean, g.rstd, g.gamma, g.k1, g.k2, dy);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
-int cnn_conv_bwd_data2(int B, int H, int W, const float* dy, const float* w, float* dx, hipStream_t s) {
+int cnn_conv_bwd_data2(int B, int H, int W, const float* dy, const BnGrad* fuse, const float* w, float* dx, hipStream_t s) {
     const size_t lds = sizeof(float) * ((size_t)32 * H * W + 32 * 9 * 16);
-    int rc = opt_in_lds(conv3x3_bwd_data_kernel<16, 32>, lds);
-    if (rc) return rc;
-    SHM_LAUNCH((conv3x3_bwd_data_kernel<16, 32>), dim3(B), dim3(256), lds, s, dy, w, dx, H, W);
+    int rc;
+    if (fuse) {
+        if ((rc = opt_in_lds(conv3x3_bwd_data_kernel<16, 32, true>, lds))) return rc;
+        SHM_LAUNCH((conv3x3_bwd_data_kernel<16, 32, true>), dim3(B), dim3(256), lds, s, dy, *fuse, w, dx, H, W);
+    } else {
+        if ((rc = opt_in_lds(conv3x3_bwd_data_kernel<16, 32, false>, lds))) return rc;
+        SHM_LAUNCH((conv3x3_bwd_data_kernel<16, 32, false>), dim3(B), dim3(256), lds, s, dy, BnGrad{}, w, dx, H, W);
+    }
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
-int cnn_conv_bwd_weight(int layer, int B, int H, int W, const float* dy, const float* x, float* part, hipStream_t s) {
+// LDS bytes of the matrix-pipe weight-gradient kernel (fused: + the pooled-cell table and the window's pooled gradient records)
+static size_t wgrad_mfma_lds(int layer, int H, int W, bool fused) {
+    const int HW = H * W, KP = (HW + 15) & ~15, XP = (H + 2) * (W + 2), npc1 = (H / 2) * (W / 2) + 1;
+    const int cin = layer == 1 ? 2 : 16, cout = layer == 1 ? 16 : 32, tiles = (cout / 16) * ((cin * 9 + 15) / 16);
+    return sizeof(float) * ((size_t)((cin * XP + 3) & ~3) + KP + (fused ? (size_t)KP + 2 * (size_t)cout * npc1 : 0) +
+                            (tiles >= 8 ? 0 : (size_t)8 * tiles * 256 + 8 * cout));
+}
+bool cnn_conv_bwd_weight_fusable(int layer, int H, int W, const float* y) {
+    return wgrad_mfma_lds(layer, H, W, true) <= 150 * 1024 && (H * W) % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
+           !getenv("SHM_CNN_VALU_WGRAD") && !getenv("SHM_CNN_UNFUSED_BN");
+}
+int cnn_conv_bwd_weight(int layer, int B, int H, int W, const float* dy, const BnGrad* fuse, const float* x, float* part, hipStream_t s) {
     int rc;
     // matrix-pipe version unless its staged window does not fit the LDS (or SHM_CNN_VALU_WGRAD is set: measurement knob)
-    const int HW = H * W, KP = (HW + 15) & ~15, XP = (H + 2) * (W + 2);
-    const int cin = layer == 1 ? 2 : 16, cout = layer == 1 ? 16 : 32, tiles = (cout / 16) * ((cin * 9 + 15) / 16);
-    const size_t lds_m = sizeof(float) * ((size_t)((cin * XP + 3) & ~3) + KP + (tiles >= 8 ? 0 : (size_t)8 * tiles * 256 + 8 * cout));
+    const int HW = H * W;
+    const size_t lds_m = wgrad_mfma_lds(layer, H, W, fuse != nullptr);
+    if (fuse) {
+        SHM_REQUIRE(cnn_conv_bwd_weight_fusable(layer, H, W, fuse->y), SHM_EINVAL, "cnn conv_bwd_weight: fused form not available for %dx%d", H, W);
+        if (layer == 1) {
+            if ((rc = opt_in_lds(conv3x3_bwd_weight_mfma_kernel<2, 16, true>, lds_m))) return rc;
+            SHM_LAUNCH((conv3x3_bwd_weight_mfma_kernel<2, 16, true>), dim3(B), dim3(512), lds_m, s, dy, *fuse, x, part, H, W);
+        } else {
+            if ((rc = opt_in_lds(conv3x3_bwd_weight_mfma_kernel<16, 32, true>, lds_m))) return rc;
+            SHM_LAUNCH((conv3x3_bwd_weight_mfma_kernel<16, 32, true>), dim3(B), dim3(512), lds_m, s, dy, *fuse, x, part, H, W);
+        }
+        SHM_LAUNCH_CHECK();
+        return SHM_OK;
+    }
     if (lds_m <= 150 * 1024 && HW % 4 == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0 && !getenv("SHM_CNN_VALU_WGRAD")) {
         if (layer == 1) {
-            if ((rc = opt_in_lds(conv3x3_bwd_weight_mfma_kernel<2, 16>, lds_m))) return rc;
-            SHM_LAUNCH((conv3x3_bwd_weight_mfma_kernel<2, 16>), dim3(B), dim3(512), lds_m, s, dy, x, part, H, W);
+            if ((rc = opt_in_lds(conv3x3_bwd_weight_mfma_kernel<2, 16, false>, lds_m))) return rc;
+            SHM_LAUNCH((conv3x3_bwd_weight_mfma_kernel<2, 16, false>), dim3(B), dim3(512), lds_m, s, dy, BnGrad{}, x, part, H, W);
         } else {
-            if ((rc = opt_in_lds(conv3x3_bwd_weight_mfma_kernel<16, 32>, lds_m))) return rc;
-            SHM_LAUNCH((conv3x3_bwd_weight_mfma_kernel<16, 32>), dim3(B), dim3(512), lds_m, s, dy, x, part, H, W);
+            if ((rc = opt_in_lds(conv3x3_bwd_weight_mfma_kernel<16, 32, false>, lds_m))) return rc;
+            SHM_LAUNCH((conv3x3_bwd_weight_mfma_kernel<16, 32, false>), dim3(B), dim3(512), lds_m, s, dy, BnGrad{}, x, part, H, W);
         }
         SHM_LAUNCH_CHECK();
         return SHM_OK;

@@ -286,12 +286,13 @@ def test_split_time_chunked_layer_pipeline_equals_one_launch_per_layer(nc, monke
         monkeypatch.setenv("SHM_SP_CHUNKS", str(chunks))
         torch.manual_seed(3)
         m = TemporalVAE(4, 16, 128, 2, 0.3, precision="split").cuda().train()
+        m.eval()
+        with torch.no_grad(), inject_eps([eps.cpu()]):          # inference forward on the initial weights (the step below moves them)
+            rec, mu, lv = m(x)
+        m.train()
         tr = VAETrainer(m, lr=1e-3, weight_decay=1e-5, max_norm=2.0)
         stats = tr.step(x, 0.5, eps=eps, drop_seed=77).cpu().numpy()
         tr.check(stats)
-        m.eval()
-        with torch.no_grad(), inject_eps([eps.cpu()]):
-            rec, mu, lv = m(x)
         out[chunks] = (stats, tr.grads.clone(), rec, mu, lv)
     a, b = out[1], out[nc]
     assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
