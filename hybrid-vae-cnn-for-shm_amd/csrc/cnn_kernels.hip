@@ -875,10 +875,16 @@ __global__ void __launch_bounds__(512) conv3x3_bwd_weight_mfma_kernel(const floa
             cm[m] = bn.mean[c]; crs[m] = bn.rstd[c]; csc[m] = bn.gamma[c] * bn.rstd[c]; ck1[m] = bn.k1[c]; ck2[m] = bn.k2[c];
         } else { cm[m] = crs[m] = csc[m] = ck1[m] = ck2[m] = 0.f; }
     }
-    // positions kb*16 + 4q .. +3 of this lane's dy row of M-tile m (zero past the window); arow: the row in dy, or in y (FUSE)
-    auto a_load = [&](const float* arow, int kb, int m) -> f32x4 {
+    // positions kb*16 + 4q .. +3 of this lane's dy row of M-tile m (zero past the window); arow: the row in dy, or in y (FUSE).
+    // Two halves so that the ring really prefetches: a_issue starts the 16-byte global read (and, FUSE, resolves the four pooled
+    // gradients from LDS); a_value, called when the k-block is consumed, is the first use of the global data (FUSE: the BatchNorm
+    // backward formula).  With the formula inside the issue half every k-block waited out its own global read: 46 vs 20 us (conv1).
+    struct ARaw { f32x4 v; f32x4 da; };
+    auto a_issue = [&](const float* arow, int kb, int m) -> ARaw {
         const int kk = kb < NKB ? kb : NKB - 1, p = kk * 16 + 4 * q;
-        f32x4 v = *reinterpret_cast<const f32x4*>(arow + (p < HW ? p : 0));
+        ARaw r;
+        r.v = *reinterpret_cast<const f32x4*>(arow + (p < HW ? p : 0));
+        r.da = zero4;
         if constexpr (FUSE) {
             const int4 pr = *reinterpret_cast<const int4*>(pref + kk * 16 + 4 * q);
             const f32x2* pcr = pc + (size_t)(m * 16 + j) * NPC1;
@@ -886,11 +892,18 @@ __global__ void __launch_bounds__(512) conv3x3_bwd_weight_mfma_kernel(const floa
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const f32x2 rec = pcr[prs[e] >> 2];
-                const float da = __float_as_int(rec[1]) == (prs[e] & 3) ? rec[0] : 0.f;
-                v[e] = csc[m] * (da - ck1[m] - (v[e] - cm[m]) * crs[m] * ck2[m]);
+                r.da[e] = __float_as_int(rec[1]) == (prs[e] & 3) ? rec[0] : 0.f;
             }
         }
-        return p < HW ? v : zero4;
+        return r;
+    };
+    auto a_value = [&](const ARaw& r, int kb, int m) -> f32x4 {
+        f32x4 v = r.v;
+        if constexpr (FUSE) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = csc[m] * (r.da[e] - ck1[m] - (v[e] - cm[m]) * crs[m] * ck2[m]);
+        }
+        return kb * 16 + 4 * q < HW ? v : zero4;
     };
     const float* arows = FUSE ? bn.y + (size_t)b * COUT * HW : dyb;
     if constexpr (TILE_PAR) {
@@ -900,16 +913,16 @@ __global__ void __launch_bounds__(512) conv3x3_bwd_weight_mfma_kernel(const floa
 #pragma unroll
         for (int i = 0; i < NTW; ++i) { column(nt0 + (i < ntn ? i : 0), boff[i], keep[i]); acc[i] = zero4; }
         const float* arow = arows + (size_t)(mt * 16 + j) * HW;
-        f32x4 ar[PF];
+        ARaw ar[PF];
 #pragma unroll
-        for (int u = 0; u < PF; ++u) ar[u] = a_load(arow, u, mt);
+        for (int u = 0; u < PF; ++u) ar[u] = a_issue(arow, u, mt);
         float bsum = 0.f;
         for (int kb0 = 0; kb0 < NKB; kb0 += PF) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 const int kb = kb0 + u;
                 if (kb < NKB) {
-                    const f32x4 a = ar[u];
+                    const f32x4 a = a_value(ar[u], kb, mt);
                     bsum += (a[0] + a[1]) + (a[2] + a[3]);
                     const int* pp = posoff + kb * 16 + 4 * q;
                     const int p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3];
@@ -923,7 +936,7 @@ __global__ void __launch_bounds__(512) conv3x3_bwd_weight_mfma_kernel(const floa
                             acc[i] = mfma_f32_16x16x4(a[3], xb[p3] * keep[i], acc[i]);
                         }
                 }
-                ar[u] = a_load(arow, kb + PF, mt);
+                ar[u] = a_issue(arow, kb + PF, mt);
             }
         }
 #pragma unroll
@@ -947,11 +960,11 @@ __global__ void __launch_bounds__(512) conv3x3_bwd_weight_mfma_kernel(const floa
 #pragma unroll
         for (int m = 0; m < MT; ++m) bsum[m] = 0.f;
         // wave w takes k-blocks w, w + 8, ...; the ring holds the next PF of them
-        f32x4 ar[PF][MT];
+        ARaw ar[PF][MT];
 #pragma unroll
         for (int u = 0; u < PF; ++u)
 #pragma unroll
-            for (int m = 0; m < MT; ++m) ar[u][m] = a_load(arows + (size_t)(m * 16 + j) * HW, wave + u * NWV, m);
+            for (int m = 0; m < MT; ++m) ar[u][m] = a_issue(arows + (size_t)(m * 16 + j) * HW, wave + u * NWV, m);
         for (int kb0 = wave; kb0 < NKB; kb0 += PF * NWV) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
@@ -967,7 +980,7 @@ __global__ void __launch_bounds__(512) conv3x3_bwd_weight_mfma_kernel(const floa
                     }
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
-                        const f32x4 a = ar[u][m];
+                        const f32x4 a = a_value(ar[u][m], kb, m);
                         bsum[m] += (a[0] + a[1]) + (a[2] + a[3]);
 #pragma unroll
                         for (int i = 0; i < NT; ++i)
@@ -976,7 +989,7 @@ __global__ void __launch_bounds__(512) conv3x3_bwd_weight_mfma_kernel(const floa
                     }
                 }
 #pragma unroll
-                for (int m = 0; m < MT; ++m) ar[u][m] = a_load(arows + (size_t)(m * 16 + j) * HW, kb + PF * NWV, m);
+                for (int m = 0; m < MT; ++m) ar[u][m] = a_issue(arows + (size_t)(m * 16 + j) * HW, kb + PF * NWV, m);
             }
         }
         float* redb = red + (size_t)NWV * TILES * 256;          // [NWV][COUT]

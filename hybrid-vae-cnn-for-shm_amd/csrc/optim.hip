@@ -46,7 +46,8 @@ __global__ void __launch_bounds__(256) adam_kernel(int64_t n, float* __restrict_
                                                    float max_norm, float grad_scale, const float* __restrict__ partial,
                                                    float* __restrict__ out_norm) {
     __shared__ float red[4];
-    const float tot = block_sum_256(partial[threadIdx.x], red);     // NORM_BLOCKS == blockDim.x
+    // partial == nullptr: neither clipping nor the norm itself was asked for (the sumsq launch was skipped)
+    const float tot = partial ? block_sum_256(partial[threadIdx.x], red) : 0.f;     // NORM_BLOCKS == blockDim.x
     const float norm = sqrtf(tot);
     float coef = grad_scale;
     if (max_norm > 0.f) coef *= fminf(1.0f, max_norm / (norm + 1e-6f));
@@ -75,8 +76,12 @@ extern "C" int shm_adam_step(int64_t n, float* params, float* grads, float* exp_
     SHM_REQUIRE((reinterpret_cast<uintptr_t>(grads) & 15) == 0, SHM_EINVAL, "shm_adam_step: grads must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     float* partial = (float*)scratch;
-    SHM_LAUNCH(sumsq_kernel, dim3(NORM_BLOCKS), dim3(256), 0, s, grads, n, grad_scale, partial);
-    SHM_LAUNCH_CHECK();
+    // the norm costs a launch of its own: taken only when something consumes it (clipping, or the caller wants it reported)
+    const bool need_norm = max_norm > 0.f || out_norm != nullptr;
+    if (need_norm) {
+        SHM_LAUNCH(sumsq_kernel, dim3(NORM_BLOCKS), dim3(256), 0, s, grads, n, grad_scale, partial);
+        SHM_LAUNCH_CHECK();
+    } else partial = nullptr;
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     const float step_size = (float)(lr / bc1);
     const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));

@@ -160,9 +160,13 @@ class CNNTrainer:
     CrossEntropy -> backward -> [flat gradient all-reduce] -> Adam(lr 1e-4, wd 5e-5), no clipping.  BatchNorm statistics stay
     per-rank under data parallelism (plain DDP semantics)."""
 
-    def __init__(self, model, lr=1e-4, weight_decay=5e-5, betas=(0.9, 0.999), eps=1e-8, seed=42, group=None, sync_params=True):
+    def __init__(self, model, lr=1e-4, weight_decay=5e-5, betas=(0.9, 0.999), eps=1e-8, seed=42, group=None, sync_params=True,
+                 report_grad_norm=False):
+        """report_grad_norm: also return the gradient 2-norm in stats[1] (one more launch per step; the reference step neither clips
+        nor logs it, so it is off by default and stats[1] stays 0)."""
         self.model = model
         self.engine = model._engine
+        self.report_grad_norm = bool(report_grad_norm)
         self._named, self._bufs = dict(model.named_parameters()), dict(model.named_buffers())
         self.flat = self.engine.bind(self._named, self._bufs)
         dev, n = self.flat.device, self.engine.n_flat
@@ -206,7 +210,8 @@ class CNNTrainer:
         check(lib.shm_adam_step(C.c_int64(eng.n_flat), _ptr(self.flat), _ptr(self.grads), _ptr(self.exp_avg),
                                 _ptr(self.exp_avg_sq), self.step_count, C.c_float(self.lr), C.c_float(b1), C.c_float(b2),
                                 C.c_float(self.eps), C.c_float(self.wd), C.c_float(0.0), C.c_float(scale),
-                                _ptr(self.scratch), C.c_void_p(self.stats.data_ptr() + 4), _stream()), "shm_adam_step")
+                                _ptr(self.scratch), C.c_void_p(self.stats.data_ptr() + 4 if self.report_grad_norm else None), _stream()),
+              "shm_adam_step")
         # BatchNorm2d.num_batches_tracked (informational: momentum is the constant 0.1) is counted on the host and written into the two
         # int64 buffers only when somebody looks (state_dict / evaluate): two ATen launches per step otherwise
         self._nbt_pending += 1

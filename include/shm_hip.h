@@ -145,7 +145,8 @@ int  shm_vae_backward(shm_vae_plan* plan, const float* x,
 /* clip_grad_norm_(max_norm) + torch.optim.Adam step (03_train_vae.py:222,270-271) over flat buffers.
  * grad_scale multiplies the gradients first (1/world_size after a sum all-reduce).  max_norm <= 0: no clipping.
  * weight decay is L2-coupled (g += wd*p).  step is 1-based.  scratch: >= shm_adam_scratch_bytes(n) device bytes.
- * out_norm (device, 1 float, may be NULL) receives the pre-clip total norm. */
+ * out_norm (device, 1 float, may be NULL) receives the pre-clip total norm; with max_norm <= 0 AND out_norm NULL the norm is not
+ * computed at all (one launch less: the CNN step of 05_train_cnn.py:270-276 neither clips nor logs it). */
 size_t shm_adam_scratch_bytes(int64_t n);
 int  shm_adam_step(int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
                    int32_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
