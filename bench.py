@@ -368,6 +368,29 @@ PRECISION_NOTE = {
 }
 
 
+def inference_leg(data, dev, precisions=("bf16", "split")):
+    """Scoring side of the same model (04_vae_thresholding.py:232-283 / 06_test_full_pipeline.py: eval-mode forward, per-window mean
+    squared reconstruction error) on the resident synthetic windows, 512 per call: windows/s per precision.  Not the headline metric."""
+    import torch
+    from Scripts.Models.temporal_vae import TemporalVAE
+    from shm_hip.pipeline import score_windows
+    out = {}
+    for prec in precisions:
+        torch.manual_seed(42)
+        vae = TemporalVAE(D, Z, H, L, 0.3, precision=prec).to(dev).eval()
+        score_windows(vae, data[:2 * B_PER_GPU], B_PER_GPU)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 4
+        for _ in range(reps):
+            score_windows(vae, data, B_PER_GPU)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        out[prec] = {"value": round(data.size(0) / dt, 1), "unit": "windows/s", "ms_per_512": round(dt * 1e3 * B_PER_GPU / data.size(0), 4),
+                     "windows": int(data.size(0)), "what": "score_windows: eval forward + per-window MSE, ε drawn on the device"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -380,6 +403,7 @@ def main():
                          "path; fp32: exact-f32 MFMA")
     ap.add_argument("--no-parity-leg", action="store_true", help="skip the parity-grade (split) leg that follows a bf16 headline at N = 1")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the short exact-fp32 measurement (N = 1 only)")
+    ap.add_argument("--no-inference-leg", action="store_true", help="skip the scoring (inference) measurement (N = 1 only)")
     ap.add_argument("--workload", choices=["vae", "cnn"], default="vae",
                     help="vae (default): the headline LSTM-VAE train step (BASELINE.json metric); cnn: the 4DOF classifier's train step "
                          "(BASELINE.json configs[2], secondary line, N = 1 only)")
@@ -441,6 +465,8 @@ def main():
         leg = measure("fp32", data, dev, 1, 0, 6, 2, 0, dist)
         leg["precision"] = "fp32"; leg["precision_note"] = PRECISION_NOTE["fp32"]
         out["fp32_exact_path"] = leg
+    if world == 1 and not args.no_inference_leg:
+        out["inference"] = inference_leg(data, dev)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

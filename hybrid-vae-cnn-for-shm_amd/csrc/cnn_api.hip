@@ -243,13 +243,16 @@ extern "C" int shm_cnn_backward(shm_cnn_plan* p, const float* params, const floa
     const BnGrad g2{at<float>(ws, p->y2), at<float>(ws, p->dflat), at<unsigned char>(ws, p->i2), at<float>(ws, p->mean2), at<float>(ws, p->rstd2),
                     params + p->g2, at<float>(ws, p->k1), at<float>(ws, p->k2)};
     const bool fuse2 = cnn_conv_bwd_weight_fusable(2, p->H1, p->W1, g2.y);
+    // the K-split weight-gradient kernel forms every dy2 value exactly once and leaves it in the workspace: the data gradient reads it
+    const bool dy2_left = fuse2 && cnn_conv_bwd_weight_leaves_dy(2, p->H1, p->W1, g2.y);
     { KernelTimer kt("cnn.bn2_bwd", (hipStream_t)stream);
     if ((rc = cnn_bn_bwd_stats(B, C2, p->H1, p->W1, g2.dp, g2.idx, g2.y, g2.mean, g2.rstd, at<float>(ws, p->part2), at<float>(ws, p->k1), at<float>(ws, p->k2),
                                grads + p->g2, grads + p->b2, s))) return rc;
     if (!fuse2 && (rc = cnn_bn_bwd_apply(B, C2, p->H1, p->W1, g2, at<float>(ws, p->dy2), s))) return rc;
     }
     { KernelTimer kt("cnn.conv2_dw", (hipStream_t)stream);
-    if ((rc = cnn_conv_bwd_weight(2, B, p->H1, p->W1, at<float>(ws, p->dy2), fuse2 ? &g2 : nullptr, at<float>(ws, p->p1), wpart, s))) return rc;
+    if ((rc = cnn_conv_bwd_weight(2, B, p->H1, p->W1, at<float>(ws, p->dy2), fuse2 ? &g2 : nullptr, at<float>(ws, p->p1), wpart, s,
+                                  dy2_left ? at<float>(ws, p->dy2) : nullptr))) return rc;
     }
     {
         // partial rows are [C2*C1*9 weights | C2 biases]: the weight block and the bias block of every partial row, each with the row stride
@@ -258,7 +261,7 @@ extern "C" int shm_cnn_backward(shm_cnn_plan* p, const float* params, const floa
         if ((rc = reduce_jobs_add(rjobs, wpart + nw, B, (size_t)C2, n, grads + p->c2b, nullptr))) return rc;
     }
     { KernelTimer kt("cnn.conv2_dx", (hipStream_t)stream);
-    if ((rc = cnn_conv_bwd_data2(B, p->H1, p->W1, at<float>(ws, p->dy2), fuse2 ? &g2 : nullptr, params + p->c2w, at<float>(ws, p->dp1), s))) return rc;
+    if ((rc = cnn_conv_bwd_data2(B, p->H1, p->W1, at<float>(ws, p->dy2), (fuse2 && !dy2_left) ? &g2 : nullptr, params + p->c2w, at<float>(ws, p->dp1), s))) return rc;
     }
     // block 1 (k1 / k2 of block 2 are consumed: the stream orders the reuse)
     const BnGrad g1{at<float>(ws, p->y1), at<float>(ws, p->dp1), at<unsigned char>(ws, p->i1), at<float>(ws, p->mean1), at<float>(ws, p->rstd1),

@@ -108,16 +108,28 @@ __global__ void __launch_bounds__(256) conv3x3_fwd_kernel(const float* __restric
     }
 }
 
+// The pool / ReLU / BatchNorm backward of one element, for the kernels that form dy on the fly instead of reading it:
+// dy = gamma rstd (da - k1 - xhat k2), xhat = (y - mean) rstd, da = the pooled gradient if this position was the cell's first maximum.
+__device__ __forceinline__ float bn_dy(const BnGrad& g, int c, float y, float da) {
+    const float rs = g.rstd[c];
+    return g.gamma[c] * rs * (da - g.k1[c] - (y - g.mean[c]) * rs * g.k2[c]);
+}
+
 // The same convolution on the matrix pipe, exact fp32 (v_mfma_f32_16x16x4_f32): y[co][p] = b[co] + sum_k W[co][k] col[k][p] with k = ci * 9 + tap
 // in the weights' own order (no re-layout) and col = the im2col view of x (never materialised): M = 16 output channels, N = 16
 // consecutive positions, K = CIN * 9 padded to a multiple of 4.  The A fragments of a wave (all of W it needs: KS values per M-tile)
 // live in registers for the whole window; a B value is one 4-byte LDS read out of the halo-padded x at (position offset + k offset).
 // grid = B, block = 512 (8 waves, position tiles dealt round-robin).  STATS: per-channel sum / sum of squares of this window,
 // lane-local over the wave's tiles, combined by shuffles, one barrier, then a fixed-order sum over the waves.
-template <int CIN, int COUT, bool STATS>
-__global__ void __launch_bounds__(512) conv3x3_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+// DGRAD: the same kernel as the DATA gradient of a convolution — dx[ci][p] = sum_{co, tap} dy[co][p - off(tap)] W[co][ci][tap] is a
+// 3x3 convolution of dy with the weights transposed and flipped (A[ci][co][tap'] = W[co][ci][8 - tap']; CIN / COUT below are then the
+// conv's output / input channel counts), no bias, no statistics; its input dy is either read (x = dy: the K-split weight-gradient kernel
+// leaves it) or, with bn.y set, formed while staging from the pooled gradient and the saved conv output (bn_dy).  Replaces the vector kernel conv3x3_bwd_data_kernel (40 us at B = 512, LDS-bound on the
+// weight broadcasts).
+template <int CIN, int COUT, bool STATS, bool DGRAD = false>
+__global__ void __launch_bounds__(512, 4) conv3x3_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                const float* __restrict__ bias, float* __restrict__ y,
-                                                               float* __restrict__ part, int H, int W) {
+                                                               float* __restrict__ part, int H, int W, BnGrad bn) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     // MTW output-channel tiles per wave: all of them while the weights fit comfortably in registers (conv1: 1 x 5 values), ONE when
     // they would not (conv2: 36 values per tile; two tiles per wave needed 187 VGPRs = one workgroup per CU) — then the waves are
@@ -129,56 +141,157 @@ __global__ void __launch_bounds__(512) conv3x3_fwd_mfma_kernel(const float* __re
     const int mg = wave % MG, m0 = mg * MTW;                  // this wave's output-channel tiles: m0 .. m0 + MTW - 1
     float* xs = sm;                                           // [CIN][H + 2][W + 2], zero halo
     float* red = sm + ((CIN * XP + 3) & ~3);                  // STATS: [NWV][COUT][2]
-    // eight loads in flight per thread: issued one per trip, every global read would wait out its full latency before the next
-    for (int e0 = tid; e0 < CIN * XP; e0 += 512 * 8) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = e0 + u * 512, ec = e < CIN * XP ? e : 0;
-            const int ci = ec / XP, r = ec - ci * XP, hh = r / WP - 1, ww = r - (hh + 1) * WP - 1;
-            v[u] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? x[((size_t)b * CIN + ci) * HW + hh * W + ww] : 0.f;
+    int* tab = reinterpret_cast<int*>(red + NWV * COUT * 2);  // [XP] per halo cell: source position p (bits 0-11, 0xFFF = halo), DGRAD: pooled cell << 12, sel << 28
+    float* cst = reinterpret_cast<float*>(tab + ((XP + 3) & ~3));   // DGRAD: [CIN][4] = gamma rstd, k1, mean, rstd k2
+    // The halo geometry (two divisions per cell) is worked out ONCE per workgroup into `tab`; the staging loop then walks (channel, cell)
+    // incrementally — with the divisions inside it, staging was most of this kernel at CIN = 32.
+    {
+        const int Hp = H / 2, Wp = W / 2;
+        for (int r = tid; r < XP; r += 512) {
+            const int hh = r / WP - 1, ww = r - (hh + 1) * WP - 1;
+            const bool in = hh >= 0 && hh < H && ww >= 0 && ww < W, pooled = in && (hh >> 1) < Hp && (ww >> 1) < Wp;
+            tab[r] = (in ? hh * W + ww : 0xFFF) | (pooled ? ((hh >> 1) * Wp + (ww >> 1)) << 12 | ((hh & 1) * 2 + (ww & 1)) << 28 : 7 << 28);
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (e0 + u * 512 < CIN * XP) xs[e0 + u * 512] = v[u];
+        if (DGRAD && bn.y)
+            for (int c = tid; c < CIN; c += 512) {
+                const float rs = bn.rstd[c];
+                cst[c * 4] = bn.gamma[c] * rs; cst[c * 4 + 1] = bn.k1[c]; cst[c * 4 + 2] = bn.mean[c]; cst[c * 4 + 3] = rs * bn.k2[c];
+            }
     }
-    // A: lane (q, j) holds W[(m0 + m) * 16 + j][4 s + q]; B offsets: k = 4 s + q -> (ci, tap) -> ci * XP + dh * WP + dw
-    float a[MTW][KS];
-    int koff[KS];
+    __syncthreads();
+    {
+        // eight cells in flight per thread: issued one per trip, every global read would wait out its full latency before the next
+        const int npc = (H / 2) * (W / 2);
+        int ci = tid / XP, r = tid - ci * XP;                 // cell e = tid + 512 k  ->  (ci, r), advanced without dividing
+        for (int e0 = tid; e0 < CIN * XP; e0 += 512 * 8) {
+            float v[8], dv[8];
+            int kk[8], cc[8];
 #pragma unroll
-    for (int s2 = 0; s2 < KS; ++s2) {
-        const int k = 4 * s2 + q, ok = k < NK, kk = ok ? k : 0, ci = kk / 9, tap = kk - ci * 9;
-        koff[s2] = ci * XP + (tap / 3 - 1) * WP + (tap % 3 - 1);
+            for (int u = 0; u < 8; ++u) {
+                const int cu = ci < CIN ? ci : CIN - 1, t = tab[r], p = t & 0xFFF;
+                const bool in = p != 0xFFF;
+                if (DGRAD && bn.y) {
+                    const size_t pe = ((size_t)b * CIN + cu) * npc + ((t >> 28) < 4 ? (t >> 12) & 0xFFFF : 0);
+                    v[u] = bn.y[((size_t)b * CIN + cu) * HW + (in ? p : 0)];
+                    dv[u] = bn.dp[pe];
+                    kk[u] = !in ? -2 : ((int)bn.idx[pe] == (t >> 28)) ? 1 : 0;      // -2 halo, 1 this position took the pooled gradient
+                } else {
+                    const float xv = x[((size_t)b * CIN + cu) * HW + (in ? p : 0)];
+                    v[u] = in ? xv : 0.f;
+                }
+                cc[u] = cu;
+                r += 512;
+                while (r >= XP) { r -= XP; ++ci; }
+            }
 #pragma unroll
-        for (int m = 0; m < MTW; ++m) a[m][s2] = ok ? w[(size_t)((m0 + m) * 16 + j) * NK + k] : 0.f;      // zero weight: the padded k contributes nothing
+            for (int u = 0; u < 8; ++u)
+                if (e0 + u * 512 < CIN * XP) {
+                    if (DGRAD && bn.y) {
+                        const f32x4 c4 = *reinterpret_cast<const f32x4*>(cst + cc[u] * 4);
+                        xs[e0 + u * 512] = kk[u] == -2 ? 0.f : c4[0] * ((kk[u] == 1 ? dv[u] : 0.f) - c4[1] - (v[u] - c4[2]) * c4[3]);
+                    } else xs[e0 + u * 512] = v[u];
+                }
+        }
     }
+    // K order.  CIN % 4 == 0 (conv2): k = tap * CIN + ci, so the k-step s = k / 4 of lane quarter q is channel 4 (s % (CIN/4)) + q at tap
+    // s / (CIN/4): the B address is (this lane's position + q * XP) + a wave-uniform offset per k-step — no per-lane offset table
+    // (36 registers at CIN = 16), which is what lets the B reads of a whole tile be issued as a block.  Otherwise (conv1, K = 18): the
+    // weights' own order k = ci * 9 + tap with a per-lane table of KS offsets.
+    // A: lane (q, j) holds W[(m0 + m) * 16 + j][k(s, q)].
+    constexpr bool TAPMAJOR = CIN % 4 == 0;
+    constexpr int CQ = TAPMAJOR ? CIN / 4 : 1;
+    // A lives in registers for the whole window (every position tile reuses it) unless K is long (DGRAD of conv2: 72 k-steps) — then a
+    // wave walks its position tiles in ONE trip and fetches each A value as it is used (ASTREAM; L1 / L2 hits, 147 -> <= 128 VGPRs,
+    // i.e. two workgroups per CU instead of one).
+    constexpr bool ASTREAM = KS > 40;
+    auto a_val = [&](int m, int s2, int& koff_out) -> float {
+        int k, ok;
+        if constexpr (TAPMAJOR) {
+            const int ci = 4 * (s2 % CQ) + q, tap = s2 / CQ;
+            k = ci * 9 + tap; ok = 1; koff_out = 0;
+        } else {
+            k = 4 * s2 + q; ok = k < NK;
+            const int kk = ok ? k : 0, ci = kk / 9, tap = kk - ci * 9;
+            koff_out = ci * XP + (tap / 3 - 1) * WP + (tap % 3 - 1);
+            k = kk;
+        }
+        const int o = (m0 + m) * 16 + j;
+        if constexpr (DGRAD) { const int ci = k / 9, tap = k - ci * 9; return ok ? w[((size_t)ci * COUT + o) * 9 + (8 - tap)] : 0.f; }
+        else return ok ? w[(size_t)o * NK + k] : 0.f;          // zero weight: the padded k contributes nothing
+    };
+    float a[MTW][ASTREAM ? 1 : KS];
+    int koff[TAPMAJOR ? 1 : KS];
+    int qoff = 0;
+    if constexpr (!ASTREAM) {
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2)
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) { int ko; a[m][s2] = a_val(m, s2, ko); if constexpr (!TAPMAJOR) koff[s2] = ko; }
+    }
+    if constexpr (TAPMAJOR) qoff = q * XP;
+    auto boff = [&](int s2) -> int {                          // B offset of k-step s2 relative to the lane's (position [+ q * XP]) address
+        if constexpr (TAPMAJOR) { const int tap = s2 / CQ; return 4 * (s2 % CQ) * XP + (tap / 3 - 1) * WP + (tap % 3 - 1); }
+        else return koff[s2];
+    };
     float bia[MTW][4], s1[MTW][4], s2v[MTW][4];
 #pragma unroll
     for (int m = 0; m < MTW; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { bia[m][r] = bias[(m0 + m) * 16 + 4 * q + r]; s1[m][r] = 0.f; s2v[m][r] = 0.f; }
+        for (int r = 0; r < 4; ++r) { bia[m][r] = DGRAD ? 0.f : bias[(m0 + m) * 16 + 4 * q + r]; s1[m][r] = 0.f; s2v[m][r] = 0.f; }
     __syncthreads();
-    for (int nt = wave / MG; nt < ntiles; nt += NWV / MG) {
-        const int p = nt * 16 + j, pc = p < HW ? p : HW - 1, h = pc / W, ww = pc - h * W;
-        const float* xb = xs + (h + 1) * WP + (ww + 1);
-        f32x4 acc[MTW];
+    // Two position tiles per trip (two independent accumulator chains per output-channel tile), their B values read from LDS in blocks
+    // of KB k-steps BEFORE the block's MFMAs: written as read-one / multiply-one the compiler waited out the LDS latency in front of
+    // every MFMA (matrix pipe 19 % busy, 40 us for conv2 at B = 512).
+    constexpr int KB = KS < 12 ? KS : 12, NTI = 2;
+    const int stride_t = NWV / MG;
+    for (int nt0 = wave / MG; nt0 < ntiles; nt0 += NTI * stride_t) {
+        const float* xb[NTI];
+        int pp[NTI];
+        f32x4 acc[NTI][MTW];
 #pragma unroll
-        for (int m = 0; m < MTW; ++m) acc[m] = f32x4{bia[m][0], bia[m][1], bia[m][2], bia[m][3]};
+        for (int t = 0; t < NTI; ++t) {
+            const int nt = nt0 + t * stride_t;
+            pp[t] = nt < ntiles ? nt * 16 + j : HW;              // HW = "no position": computed on a valid cell, never stored
+            const int pc = pp[t] < HW ? pp[t] : HW - 1, h = pc / W, ww = pc - h * W;
+            xb[t] = xs + (h + 1) * WP + (ww + 1) + qoff;
 #pragma unroll
-        for (int s3 = 0; s3 < KS; ++s3) {
-            const float bv = xb[koff[s3]];
-#pragma unroll
-            for (int m = 0; m < MTW; ++m) acc[m] = mfma_f32_16x16x4(a[m][s3], bv, acc[m]);
+            for (int m = 0; m < MTW; ++m) acc[t][m] = f32x4{bia[m][0], bia[m][1], bia[m][2], bia[m][3]};
         }
-        if (p < HW) {
 #pragma unroll
-            for (int m = 0; m < MTW; ++m)
+        for (int s0 = 0; s0 < KS; s0 += KB) {
+            float bv[NTI][KB], av[MTW][KB];
+            if constexpr (ASTREAM) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = acc[m][r];
-                    y[((size_t)b * COUT + (m0 + m) * 16 + 4 * q + r) * HW + p] = v;
-                    if (STATS) { s1[m][r] += v; s2v[m][r] = fmaf(v, v, s2v[m][r]); }
-                }
+                for (int u = 0; u < KB; ++u)
+#pragma unroll
+                    for (int m = 0; m < MTW; ++m) { int ko; if (s0 + u < KS) av[m][u] = a_val(m, s0 + u, ko); }
+            }
+#pragma unroll
+            for (int u = 0; u < KB; ++u)
+#pragma unroll
+                for (int t = 0; t < NTI; ++t)
+                    if (s0 + u < KS) bv[t][u] = xb[t][boff(s0 + u)];
+#pragma unroll
+            for (int u = 0; u < KB; ++u)
+#pragma unroll
+                for (int t = 0; t < NTI; ++t)
+#pragma unroll
+                    for (int m = 0; m < MTW; ++m)
+                        if (s0 + u < KS) acc[t][m] = mfma_f32_16x16x4(ASTREAM ? av[m][u] : a[m][s0 + u], bv[t][u], acc[t][m]);
+        }
+#pragma unroll
+        for (int t = 0; t < NTI; ++t) {
+            const int p = pp[t];
+            if (p < HW) {
+#pragma unroll
+                for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = acc[t][m][r];
+                        y[((size_t)b * COUT + (m0 + m) * 16 + 4 * q + r) * HW + p] = v;
+                        if (STATS) { s1[m][r] += v; s2v[m][r] = fmaf(v, v, s2v[m][r]); }
+                    }
+            }
         }
     }
     if (STATS) {
@@ -659,13 +772,6 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(int C, int H, int W, 
     }
 }
 
-// The pool / ReLU / BatchNorm backward of one element, for the kernels that form dy on the fly instead of reading it:
-// dy = gamma rstd (da - k1 - xhat k2), xhat = (y - mean) rstd, da = the pooled gradient if this position was the cell's first maximum.
-__device__ __forceinline__ float bn_dy(const BnGrad& g, int c, float y, float da) {
-    const float rs = g.rstd[c];
-    return g.gamma[c] * rs * (da - g.k1[c] - (y - g.mean[c]) * rs * g.k2[c]);
-}
-
 // ------------------------------------------------------------------------------------------------ conv backward
 // data gradient: dx[ci][h][w] = sum_co sum_k dy[co][h+1-kh][w+1-kw] W[co][ci][kh][kw]      grid = B
 // FUSE: dy is not read but formed while staging, from the pooled gradient and the saved conv output (bn_dy above) — the separate
@@ -1019,6 +1125,152 @@ __global__ void __launch_bounds__(512) conv3x3_bwd_weight_mfma_kernel(const floa
     }
 }
 
+// Weight gradient of a layer with many output tiles (conv2: 2 x 9), BatchNorm backward fused, K-SPLIT form.  The tile-parallel form above
+// gives every wave a few column tiles and ALL positions, so the four waves that share an output-channel tile each rebuild the same A
+// operand (the fused dy: ~50 VALU per k-block) — the kernel was VALU-issue-bound (3400 VALU per wave for 144 MFMAs; 44 us at B = 512).
+// (HW % 4 == 0, so a lane's four positions are all inside the window or all outside.)
+// Here wave (mt, ks) owns output-channel tile mt, ALL NT column tiles (NT accumulators) and every KSL-th k-block: each dy value is formed
+// exactly once per workgroup, every B value read feeds one MFMA as before, and the KSL partial sums meet in a fixed-order tree through
+// LDS (the staged operands' space is reused once every wave is done with them).  Requires CIN * 9 % 16 == 0, H * W % 4 == 0.
+template <int CIN, int COUT>
+__global__ void __launch_bounds__(512, 4) conv3x3_bwd_weight_ksplit_kernel(BnGrad bn, const float* __restrict__ x, float* __restrict__ part,
+                                                                           float* __restrict__ dy_out, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int NCOL = CIN * 9, MT = COUT / 16, NT = NCOL / 16, NWV = 8, KSL = NWV / MT, NW_ = COUT * NCOL;
+    static_assert(NCOL % 16 == 0 && KSL == 4, "conv2-shaped layers only");
+    const int HW = H * W, KP = (HW + 15) & ~15, NKB = KP / 16, WP = W + 2, XP = (H + 2) * WP, XPP = (CIN * XP + 3) & ~3;
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
+    const int Hp = H / 2, Wp = W / 2, npc = Hp * Wp, NPC1 = npc + 1;
+    const int mt = wave % MT, ks = wave / MT;
+    float* xs = sm;                                           // [CIN][H + 2][W + 2], zero halo
+    int* posoff = reinterpret_cast<int*>(xs + XPP);           // [KP]: (h + 1) * WP + (w + 1) of position p
+    int* pref = posoff + KP;                                  // [KP] pooled cell << 2 | (h & 1) * 2 + (w & 1); cell npc = "no cell"
+    f32x2* pc = reinterpret_cast<f32x2*>(pref + KP);          // [COUT][npc + 1] (pooled gradient, argmax as int bits)
+    // [KSL][COUT] row sums (bias gradient): behind the operands AND behind the exchange buffer that later overlays them (small windows)
+    const size_t opnd = (size_t)XPP + 2 * (size_t)KP + 2 * (size_t)COUT * NPC1, xchg = (size_t)2 * MT * NT * 256;
+    float* redb = sm + (opnd > xchg ? opnd : xchg);
+    for (int e = tid; e < CIN * XP; e += 512) xs[e] = 0.f;
+    for (int p = tid; p < KP; p += 512) {
+        const int h = p / W, w2 = p - h * W, hp = h >> 1, wp = w2 >> 1;
+        posoff[p] = p < HW ? (h + 1) * WP + (w2 + 1) : WP + 1;            // padding: any valid cell (dy is 0 there)
+        pref[p] = ((p < HW && hp < Hp && wp < Wp) ? hp * Wp + wp : npc) << 2 | ((h & 1) * 2 + (w2 & 1));
+    }
+    __syncthreads();
+    {
+        // interior of the halo'd window: coalesced reads, eight in flight, (channel, position) advanced without dividing
+        int ci = tid / HW, p = tid - ci * HW;
+        for (int e0 = tid; e0 < CIN * HW; e0 += 512 * 8) {
+            float v[8]; int dst[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int cu = ci < CIN ? ci : CIN - 1;
+                v[u] = x[((size_t)b * CIN + cu) * HW + p];
+                dst[u] = cu * XP + posoff[p];
+                p += 512;
+                while (p >= HW) { p -= HW; ++ci; }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (e0 + u * 512 < CIN * HW) xs[dst[u]] = v[u];
+        }
+        int co = tid / NPC1, cell = tid - co * NPC1;
+        for (int e0 = tid; e0 < COUT * NPC1; e0 += 512 * 4) {
+            float dv[4]; int kv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int cu = co < COUT ? co : COUT - 1;
+                const size_t pe = ((size_t)b * COUT + cu) * npc + (cell < npc ? cell : 0);
+                dv[u] = bn.dp[pe]; kv[u] = cell < npc ? (int)bn.idx[pe] : 4;
+                cell += 512;
+                while (cell >= NPC1) { cell -= NPC1; ++co; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (e0 + u * 512 < COUT * NPC1) pc[e0 + u * 512] = f32x2{dv[u], __int_as_float(kv[u])};
+        }
+    }
+    // this lane's A row is channel mt * 16 + j; its B columns are n = nt * 16 + j -> (ci, tap)
+    const int c = mt * 16 + j;
+    const float cm = bn.mean[c], crs = bn.rstd[c], csc = bn.gamma[c] * crs, ck1 = bn.k1[c], ck2 = bn.k2[c];
+    int boff[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { const int n = nt * 16 + j, ci = n / 9, tap = n - ci * 9; boff[nt] = ci * XP + (tap / 3 - 1) * WP + (tap % 3 - 1); }
+    const float* arow = bn.y + ((size_t)b * COUT + c) * HW;
+    const f32x2* pcr = pc + (size_t)c * NPC1;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = zero4;
+    float bsum = 0.f;
+    __syncthreads();
+    // the wave's k-blocks: ks, ks + KSL, ...; the global halves of up to PF of them in flight (see a_issue / a_value above)
+    constexpr int PF = 4;
+    f32x4 yv[PF];
+    auto y_load = [&](int kb) -> f32x4 { const int kk = kb < NKB ? kb : NKB - 1, p = kk * 16 + 4 * q; return *reinterpret_cast<const f32x4*>(arow + (p < HW ? p : 0)); };
+#pragma unroll
+    for (int u = 0; u < PF; ++u) yv[u] = y_load(ks + u * KSL);
+    for (int kb0 = ks; kb0 < NKB; kb0 += PF * KSL) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int kb = kb0 + u * KSL;
+            if (kb < NKB) {
+                const int4 pr = *reinterpret_cast<const int4*>(pref + kb * 16 + 4 * q);
+                const int4 po = *reinterpret_cast<const int4*>(posoff + kb * 16 + 4 * q);
+                const int prs[4] = {pr.x, pr.y, pr.z, pr.w}, pos[4] = {po.x, po.y, po.z, po.w};
+                f32x4 a;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const f32x2 rec = pcr[prs[e] >> 2];
+                    const float da = __float_as_int(rec[1]) == (prs[e] & 3) ? rec[0] : 0.f;
+                    a[e] = kb * 16 + 4 * q + e < HW ? csc * (da - ck1 - (yv[u][e] - cm) * crs * ck2) : 0.f;
+                }
+                bsum += (a[0] + a[1]) + (a[2] + a[3]);
+                // every dy value exists exactly once in this grid: leave it for the data-gradient kernel (16 bytes per lane, coalesced
+                // per row), which then stages plain values instead of redoing the pooled-gradient gathers and the formula
+                if (dy_out && kb * 16 + 4 * q < HW) *reinterpret_cast<f32x4*>(dy_out + ((size_t)b * COUT + c) * HW + kb * 16 + 4 * q) = a;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float bv[NT];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bv[nt] = xs[boff[nt] + pos[e]];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_f32_16x16x4(a[e], bv[nt], acc[nt]);
+                }
+            }
+            yv[u] = y_load(kb + PF * KSL);
+        }
+    }
+    bsum += __shfl_xor(bsum, 16, 64); bsum += __shfl_xor(bsum, 32, 64);
+    __syncthreads();                                           // every wave is done with xs / pc: their space becomes the exchange buffer
+    f32x4* red = reinterpret_cast<f32x4*>(sm);                 // [2][MT][NT][64] accumulators
+    if (q == 0) redb[ks * COUT + c] = bsum;
+    if (ks >= 2) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) red[((size_t)((ks - 2) * MT + mt) * NT + nt) * 64 + lane] = acc[nt];
+    }
+    __syncthreads();
+    if (ks < 2) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] += red[((size_t)(ks * MT + mt) * NT + nt) * 64 + lane];      // slice 0 += 2, slice 1 += 3
+    }
+    __syncthreads();
+    if (ks == 1) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) red[((size_t)mt * NT + nt) * 64 + lane] = acc[nt];
+    }
+    __syncthreads();
+    float* out = part + (size_t)b * (NW_ + COUT);
+    if (ks == 0) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const f32x4 v = acc[nt] + red[((size_t)mt * NT + nt) * 64 + lane];                                  // (0 + 2) + (1 + 3)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(size_t)(mt * 16 + 4 * q + r) * NCOL + nt * 16 + j] = v[r];
+        }
+    }
+    for (int e = tid; e < COUT; e += 512) out[NW_ + e] = (redb[e] + redb[2 * COUT + e]) + (redb[COUT + e] + redb[3 * COUT + e]);
+}
+
 template <typename K>
 int opt_in_lds(K kern, size_t lds) {
     SHM_REQUIRE(lds <= 160 * 1024, SHM_EINVAL, "cnn: window needs %zu bytes of LDS (> 160 KiB): T*D too large", lds);
@@ -1029,27 +1281,31 @@ int opt_in_lds(K kern, size_t lds) {
 }  // namespace
 
 // =================================================================================================== launchers
+// LDS bytes of conv3x3_fwd_mfma_kernel: halo'd window | statistics rows | halo geometry table | (DGRAD) channel constants
+static size_t conv_mfma_lds(int cin, int cout, int H, int W) {
+    const size_t XP = (size_t)(H + 2) * (W + 2);
+    return sizeof(float) * (((cin * XP + 3) & ~(size_t)3) + 8 * (size_t)cout * 2 + ((XP + 3) & ~(size_t)3) + 4 * (size_t)cin);
+}
 template <int CIN, int COUT>
 int conv_fwd_mfma(int B, int H, int W, const float* x, const float* w, const float* bias, float* y, float* part, hipStream_t s) {
-    const size_t lds = sizeof(float) * ((size_t)((CIN * (H + 2) * (W + 2) + 3) & ~3) + 8 * COUT * 2);
+    const size_t lds = conv_mfma_lds(CIN, COUT, H, W);
     int rc;
     if (part) { if ((rc = opt_in_lds(conv3x3_fwd_mfma_kernel<CIN, COUT, true>, lds))) return rc;
-                SHM_LAUNCH((conv3x3_fwd_mfma_kernel<CIN, COUT, true>), dim3(B), dim3(512), lds, s, x, w, bias, y, part, H, W); }
+                SHM_LAUNCH((conv3x3_fwd_mfma_kernel<CIN, COUT, true>), dim3(B), dim3(512), lds, s, x, w, bias, y, part, H, W, BnGrad{}); }
     else { if ((rc = opt_in_lds(conv3x3_fwd_mfma_kernel<CIN, COUT, false>, lds))) return rc;
-           SHM_LAUNCH((conv3x3_fwd_mfma_kernel<CIN, COUT, false>), dim3(B), dim3(512), lds, s, x, w, bias, y, part, H, W); }
+           SHM_LAUNCH((conv3x3_fwd_mfma_kernel<CIN, COUT, false>), dim3(B), dim3(512), lds, s, x, w, bias, y, part, H, W, BnGrad{}); }
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
 int cnn_conv_fwd(int layer, int B, int H, int W, const float* x, const float* w, const float* bias, float* y, float* part, hipStream_t s) {
     const int HW = H * W;
     int rc;
-    // conv1 (2 -> 16 channels, memory-bound) runs on the matrix pipe: 16 vs 29 us at the north-star shape.  conv2 as the same kernel
-    // (one output-channel tile per wave, 119 VGPRs, two workgroups per CU) beats the vector kernel below at small batches (eval
-    // 0.071 vs 0.088 ms at the reference's 100-window batches) and only ties it at B = 512 (same-box A/B: train 0.351 vs 0.354 ms,
-    // eval 0.086 vs 0.085), so larger batches stay on the vector path.  SHM_CNN_VALU_CONV / SHM_CNN_MFMA_CONV2: measurement knobs.
+    // Both convolutions run on the matrix pipe.  conv1 (2 -> 16 channels, memory-bound): 16 vs 29 us at the north-star shape.  conv2:
+    // 23 vs 40 us for the vector kernel below at B = 512 since round 2 (B reads issued in blocks, two position tiles in flight;
+    // before that the two tied).  SHM_CNN_VALU_CONV: measurement knob.
     if (!getenv("SHM_CNN_VALU_CONV")) {
         if (layer == 1) return conv_fwd_mfma<2, 16>(B, H, W, x, w, bias, y, part, s);
-        if (B <= 256 || getenv("SHM_CNN_MFMA_CONV2")) return conv_fwd_mfma<16, 32>(B, H, W, x, w, bias, y, part, s);
+        return conv_fwd_mfma<16, 32>(B, H, W, x, w, bias, y, part, s);
     }
     if (layer == 1) {
         const size_t lds = sizeof(float) * (((2 * HW + 3) & ~3) + 2 * 9 * 16 + 8 * 16);
@@ -1160,6 +1416,14 @@ int cnn_bn_bwd_apply(int B, int C, int H, int W, const BnGrad& g, float* dy, hip
 int cnn_conv_bwd_data2(int B, int H, int W, const float* dy, const BnGrad* fuse, const float* w, float* dx, hipStream_t s) {
     const size_t lds = sizeof(float) * ((size_t)32 * H * W + 32 * 9 * 16);
     int rc;
+    // matrix-pipe form (the forward kernel on transposed / flipped weights, dy formed while staging) when the halo'd window fits
+    const size_t lds_m = conv_mfma_lds(32, 16, H, W);
+    if (lds_m <= 150 * 1024 && !getenv("SHM_CNN_VALU_DGRAD")) {
+        if ((rc = opt_in_lds(conv3x3_fwd_mfma_kernel<32, 16, false, true>, lds_m))) return rc;
+        SHM_LAUNCH((conv3x3_fwd_mfma_kernel<32, 16, false, true>), dim3(B), dim3(512), lds_m, s, dy, w, nullptr, dx, nullptr, H, W, fuse ? *fuse : BnGrad{});
+        SHM_LAUNCH_CHECK();
+        return SHM_OK;
+    }
     if (fuse) {
         if ((rc = opt_in_lds(conv3x3_bwd_data_kernel<16, 32, true>, lds))) return rc;
         SHM_LAUNCH((conv3x3_bwd_data_kernel<16, 32, true>), dim3(B), dim3(256), lds, s, dy, *fuse, w, dx, H, W);
@@ -1181,7 +1445,10 @@ bool cnn_conv_bwd_weight_fusable(int layer, int H, int W, const float* y) {
     return wgrad_mfma_lds(layer, H, W, true) <= 150 * 1024 && (H * W) % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
            !getenv("SHM_CNN_VALU_WGRAD") && !getenv("SHM_CNN_UNFUSED_BN");
 }
-int cnn_conv_bwd_weight(int layer, int B, int H, int W, const float* dy, const BnGrad* fuse, const float* x, float* part, hipStream_t s) {
+bool cnn_conv_bwd_weight_leaves_dy(int layer, int H, int W, const float* y) {
+    return layer == 2 && cnn_conv_bwd_weight_fusable(layer, H, W, y) && !getenv("SHM_CNN_TILEPAR_WGRAD");
+}
+int cnn_conv_bwd_weight(int layer, int B, int H, int W, const float* dy, const BnGrad* fuse, const float* x, float* part, hipStream_t s, float* dy_out) {
     int rc;
     // matrix-pipe version unless its staged window does not fit the LDS (or SHM_CNN_VALU_WGRAD is set: measurement knob)
     const int HW = H * W;
@@ -1191,6 +1458,11 @@ int cnn_conv_bwd_weight(int layer, int B, int H, int W, const float* dy, const B
         if (layer == 1) {
             if ((rc = opt_in_lds(conv3x3_bwd_weight_mfma_kernel<2, 16, true>, lds_m))) return rc;
             SHM_LAUNCH((conv3x3_bwd_weight_mfma_kernel<2, 16, true>), dim3(B), dim3(512), lds_m, s, dy, *fuse, x, part, H, W);
+        } else if (!getenv("SHM_CNN_TILEPAR_WGRAD")) {
+            // K-split form: same staged operands + [4][32] row sums; the exchange buffer (2 x 18 KB) reuses the operands' space
+            const size_t xchg = (size_t)2 * 2 * 9 * 1024, lds_k = (lds_m > xchg ? lds_m : xchg) + sizeof(float) * 4 * 32;
+            if ((rc = opt_in_lds(conv3x3_bwd_weight_ksplit_kernel<16, 32>, lds_k))) return rc;
+            SHM_LAUNCH((conv3x3_bwd_weight_ksplit_kernel<16, 32>), dim3(B), dim3(512), lds_k, s, *fuse, x, part, dy_out, H, W);
         } else {
             if ((rc = opt_in_lds(conv3x3_bwd_weight_mfma_kernel<16, 32, true>, lds_m))) return rc;
             SHM_LAUNCH((conv3x3_bwd_weight_mfma_kernel<16, 32, true>), dim3(B), dim3(512), lds_m, s, dy, *fuse, x, part, H, W);

@@ -33,6 +33,9 @@ int cnn_bn_bwd_stats(int B, int C, int H, int W, const float* dp, const unsigned
 int cnn_bn_bwd_apply(int B, int C, int H, int W, const BnGrad& g, float* dy, hipStream_t s);
 int cnn_conv_bwd_data2(int B, int H, int W, const float* dy, const BnGrad* fuse, const float* w, float* dx, hipStream_t s);
 bool cnn_conv_bwd_weight_fusable(int layer, int H, int W, const float* y);
-int cnn_conv_bwd_weight(int layer, int B, int H, int W, const float* dy, const BnGrad* fuse, const float* x, float* part, hipStream_t s);
+// dy_out (fused form of layer 2 only, see cnn_conv_bwd_weight_leaves_dy): the kernel also writes the dy it forms, for the data gradient
+bool cnn_conv_bwd_weight_leaves_dy(int layer, int H, int W, const float* y);
+int cnn_conv_bwd_weight(int layer, int B, int H, int W, const float* dy, const BnGrad* fuse, const float* x, float* part, hipStream_t s,
+                        float* dy_out = nullptr);
 
 }  // namespace shm
