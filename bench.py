@@ -151,7 +151,7 @@ def cnn_alg_flops(name, B):
             "cnn.bwd_fused2": 2 * conv2, "cnn.bwd_fused1": conv1}.get(name, 0)
 
 
-def cnn_cpu_baseline(budget_s=15.0, max_steps=40):
+def cnn_cpu_baseline(budget_s=8.0, max_steps=40):
     """The reference CNN step on this box's host cores (oracle/torch_cpu_cnn.py: ATen conv2d / batch_norm / max_pool2d / linear / Adam)."""
     import torch
     from oracle.torch_cpu_cnn import TorchCpuCNN
@@ -178,6 +178,13 @@ def cnn_cpu_baseline(budget_s=15.0, max_steps=40):
 
 
 def cnn_workload(args):
+    """`--workload cnn`: the CNN line on its own (same contract as the headline)."""
+    if args.gpus != 1:
+        raise SystemExit("--workload cnn is a single-GPU line")
+    print(json.dumps(cnn_measure(args.steps, args.warmup, args.profile_steps, not args.no_cpu_baseline)))
+
+
+def cnn_measure(steps, warmup, profile_steps, with_cpu_baseline):
     """Secondary line (BASELINE.json configs[2]): train step of the 4DOF fault classifier (window + squared-residual channels, 2 x 256 x 4)
     at 512 windows per step, fp32 (every product on the exact-fp32 MFMA), plus the eval forward.  One GPU.  Same contract as the
     headline: roofline of the dominant kernel from HIP events in this run, cpu_baseline on the host cores."""
@@ -185,8 +192,11 @@ def cnn_workload(args):
     from Scripts.Models.cnn_model import CNN
     from shm_hip._capi import lib, check
     from shm_hip.trainer import CNNTrainer
-    if args.gpus != 1:
-        raise SystemExit("--workload cnn is a single-GPU line")
+
+    class _A:
+        pass
+    args = _A()
+    args.steps, args.warmup, args.profile_steps, args.no_cpu_baseline = steps, warmup, profile_steps, not with_cpu_baseline
     torch.manual_seed(42)
     m = CNN(2, 2, 0.5, seq_len=T, num_features=D).cuda().train()
     tr = CNNTrainer(m, lr=1e-4, weight_decay=5e-5)
@@ -241,7 +251,7 @@ def cnn_workload(args):
            "eval_forward": {"value": round(B_PER_GPU * args.steps / de, 2), "unit": "windows/s", "ms_per_batch": round(1e3 * de / args.steps, 4)}}
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cnn_cpu_baseline()
-    print(json.dumps(out))
+    return out
 
 
 def kernel_src_hashes():
@@ -404,6 +414,7 @@ def main():
     ap.add_argument("--no-parity-leg", action="store_true", help="skip the parity-grade (split) leg that follows a bf16 headline at N = 1")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the short exact-fp32 measurement (N = 1 only)")
     ap.add_argument("--no-inference-leg", action="store_true", help="skip the scoring (inference) measurement (N = 1 only)")
+    ap.add_argument("--no-cnn-leg", action="store_true", help="skip the CNN train-step object of the default line (N = 1 only)")
     ap.add_argument("--workload", choices=["vae", "cnn"], default="vae",
                     help="vae (default): the headline LSTM-VAE train step (BASELINE.json metric); cnn: the 4DOF classifier's train step "
                          "(BASELINE.json configs[2], secondary line, N = 1 only)")
@@ -467,6 +478,12 @@ def main():
         out["fp32_exact_path"] = leg
     if world == 1 and not args.no_inference_leg:
         out["inference"] = inference_leg(data, dev)
+    if world == 1 and not args.no_cnn_leg:
+        # the classifier's train step (BASELINE.json configs[2]) in the same driver-run line: its own metric / roofline / cpu_baseline
+        # object, short CPU sample (the headline's cpu_baseline above keeps the larger share of the CPU budget)
+        del data
+        torch.cuda.empty_cache()
+        out["cnn_train"] = cnn_measure(min(args.steps, 200), min(args.warmup, 20), args.profile_steps, not args.no_cpu_baseline)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

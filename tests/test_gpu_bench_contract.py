@@ -41,6 +41,12 @@ def test_default_line_has_the_contract_fields():
     assert pp["precision"] == "split" and pp["dtype"] == "bf16x2" and pp["steps"] >= 50 and pp["value"] > 1e5, pp
     _check_roofline(pp["roofline"], 2500.0)
     assert d["fp32_exact_path"]["dtype"] == "f32" and d["fp32_exact_path"]["value"] > 1e3
+    # inference side of the north star (scoring) and the classifier's train step ride in the same driver-run line
+    inf = d["inference"]
+    assert inf["bf16"]["value"] > inf["split"]["value"] > 1e5 and inf["split"]["unit"] == "windows/s"
+    cn = d["cnn_train"]
+    assert cn["metric"].startswith("windows/sec CNN train") and cn["value"] > 1e5 and cn["dtype"] == "f32"
+    assert cn["roofline"]["kernel"].startswith("cnn.") and cn["cpu_baseline"]["kind"] == "port"
 
 
 def test_default_flags_are_the_survey_protocol():
