@@ -370,9 +370,11 @@ static bool side_stream_enabled() {
 // 256 CUs, so the two recurrences share the chip).  SHM_SP_CHUNKS=N (1 = off, the default: measured in round 2 at the north-star shape,
 // NC = 2 / 4 / 8 gave 179 / 182 / 151 k windows/s against 183 k unchunked — two recurrences side by side each slow from 57 to 85-90 us
 // per 64 steps because one of them already draws ~3 TB/s of record traffic).  Chunks are whole 16-row tiles: T % (4 NC) == 0.
-static int sp_chunks(const shm_vae_plan* p) {
+static int sp_chunks(const shm_vae_plan* p, bool records) {
     const char* e = getenv("SHM_SP_CHUNKS");             // read per call: a test flips it inside one process
-    int want = e ? atoi(e) : SHM_SP_CHUNKS_DEFAULT;
+    // default: off for the training passes (measured above), 4 for a forward that saves no BPTT records (inference plans: scoring,
+    // encode / decode) — without the 402 MB record stream per layer two recurrences do fit side by side: 502 -> 561 k windows/s scored
+    int want = e ? atoi(e) : (records ? SHM_SP_CHUNKS_DEFAULT : 4);
     if (want < 1) want = 1;
     if (want > 8) want = 8;
     if (p->cfg.precision != SHM_PREC_SPLIT || p->cfg.num_layers != 2 || !side_stream_enabled()) return 1;
@@ -531,7 +533,7 @@ static int vae_forward_impl(shm_vae_plan* p, const float* x, const float* eps, c
     };
     // split-precision path: per layer [time-parallel input projection ->] recurrence with W_hh hi / lo in registers (lstm_sp.hip)
     const bool sp = c.precision == SHM_PREC_SPLIT;
-    const int NC = sp ? sp_chunks(p) : 1;
+    const int NC = sp ? sp_chunks(p, save) : 1;
     if (NC > 1 && (rc = ensure_side_stream(p))) return rc;
     auto run_stack_sp = [&](LayerInst* st, const float* in0, uint32_t stack, float* h_last) -> int {
         const int qt = ceil_div(B, SHM_WPT);
@@ -793,7 +795,7 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
         SHM_HIP_CHECK(hipEventRecord(p->ev_fork, s));
         SHM_HIP_CHECK(hipStreamWaitEvent(gs, p->ev_fork, 0));
     }
-    const int NCb = use_side ? sp_chunks(p) : 1;
+    const int NCb = use_side ? sp_chunks(p, true) : 1;
     // wide products on bf16 operands: dW_ih = dpre^T x_in (dropout re-applied) and dW_hh = dpre^T h_{t-1} in ONE launch (A read once)
     // lo planes of the split path: {A, Bin, Bh, Bx}
     struct LoPlanes { const void* A; const void* Bin; const void* Bh; const void* Bx; };
