@@ -7,6 +7,8 @@
 // (conv2 only) and weight gradients with per-window partials reduced in a fixed order (bitwise reproducible).
 // The windows are tiny (T*D <= 1200 pixels) and the step is launch/latency-bound, so the kernels favour simple,
 // fully-coalesced NCHW accesses over MFMA; one workgroup per window throughout.
+#include <type_traits>
+
 #include "cnn_kernels.hpp"
 
 namespace shm {
@@ -123,13 +125,13 @@ __device__ __forceinline__ float bn_dy(const BnGrad& g, int c, float y, float da
 // lane-local over the wave's tiles, combined by shuffles, one barrier, then a fixed-order sum over the waves.
 // DGRAD: the same kernel as the DATA gradient of a convolution — dx[ci][p] = sum_{co, tap} dy[co][p - off(tap)] W[co][ci][tap] is a
 // 3x3 convolution of dy with the weights transposed and flipped (A[ci][co][tap'] = W[co][ci][8 - tap']; CIN / COUT below are then the
-// conv's output / input channel counts), no bias, no statistics; its input dy is either read (x = dy: the K-split weight-gradient kernel
-// leaves it) or, with bn.y set, formed while staging from the pooled gradient and the saved conv output (bn_dy).  Replaces the vector kernel conv3x3_bwd_data_kernel (40 us at B = 512, LDS-bound on the
+// conv's output / input channel counts), no bias, no statistics; its input x = dy is what the K-split weight-gradient kernel leaves
+// (or the separate BatchNorm-backward launch writes).  Replaces the vector kernel conv3x3_bwd_data_kernel (40 us at B = 512, LDS-bound on the
 // weight broadcasts).
 template <int CIN, int COUT, bool STATS, bool DGRAD = false>
 __global__ void __launch_bounds__(512, 4) conv3x3_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                const float* __restrict__ bias, float* __restrict__ y,
-                                                               float* __restrict__ part, int H, int W, BnGrad bn) {
+                                                               float* __restrict__ part, int H, int W) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     // MTW output-channel tiles per wave: all of them while the weights fit comfortably in registers (conv1: 1 x 5 values), ONE when
     // they would not (conv2: 36 values per tile; two tiles per wave needed 187 VGPRs = one workgroup per CU) — then the waves are
@@ -141,56 +143,30 @@ __global__ void __launch_bounds__(512, 4) conv3x3_fwd_mfma_kernel(const float* _
     const int mg = wave % MG, m0 = mg * MTW;                  // this wave's output-channel tiles: m0 .. m0 + MTW - 1
     float* xs = sm;                                           // [CIN][H + 2][W + 2], zero halo
     float* red = sm + ((CIN * XP + 3) & ~3);                  // STATS: [NWV][COUT][2]
-    int* tab = reinterpret_cast<int*>(red + NWV * COUT * 2);  // [XP] per halo cell: source position p (bits 0-11, 0xFFF = halo), DGRAD: pooled cell << 12, sel << 28
-    float* cst = reinterpret_cast<float*>(tab + ((XP + 3) & ~3));   // DGRAD: [CIN][4] = gamma rstd, k1, mean, rstd k2
-    // The halo geometry (two divisions per cell) is worked out ONCE per workgroup into `tab`; the staging loop then walks (channel, cell)
-    // incrementally — with the divisions inside it, staging was most of this kernel at CIN = 32.
-    {
-        const int Hp = H / 2, Wp = W / 2;
-        for (int r = tid; r < XP; r += 512) {
-            const int hh = r / WP - 1, ww = r - (hh + 1) * WP - 1;
-            const bool in = hh >= 0 && hh < H && ww >= 0 && ww < W, pooled = in && (hh >> 1) < Hp && (ww >> 1) < Wp;
-            tab[r] = (in ? hh * W + ww : 0xFFF) | (pooled ? ((hh >> 1) * Wp + (ww >> 1)) << 12 | ((hh & 1) * 2 + (ww & 1)) << 28 : 7 << 28);
-        }
-        if (DGRAD && bn.y)
-            for (int c = tid; c < CIN; c += 512) {
-                const float rs = bn.rstd[c];
-                cst[c * 4] = bn.gamma[c] * rs; cst[c * 4 + 1] = bn.k1[c]; cst[c * 4 + 2] = bn.mean[c]; cst[c * 4 + 3] = rs * bn.k2[c];
-            }
-    }
+    int* pos = reinterpret_cast<int*>(red + NWV * COUT * 2);  // [HW] halo'd offset (h + 1) * WP + (w + 1) of position p
+    // Staging: the halo is only ever zero, so it is stored, not loaded — zero-fill, then scatter the CIN * HW interior values with their
+    // halo'd offsets from a table built once per workgroup (the two divisions per cell used to sit inside the staging loop, and every
+    // halo cell cost a masked load).  SU loads in flight per thread: a 16-channel 256-position window is one batch of 8.
+    for (int e = tid; e < CIN * XP; e += 512) xs[e] = 0.f;
+    for (int p = tid; p < HW; p += 512) { const int h = p / W; pos[p] = (h + 1) * WP + (p - h * W) + 1; }
     __syncthreads();
     {
-        // eight cells in flight per thread: issued one per trip, every global read would wait out its full latency before the next
-        const int npc = (H / 2) * (W / 2);
-        int ci = tid / XP, r = tid - ci * XP;                 // cell e = tid + 512 k  ->  (ci, r), advanced without dividing
-        for (int e0 = tid; e0 < CIN * XP; e0 += 512 * 8) {
-            float v[8], dv[8];
-            int kk[8], cc[8];
+        constexpr int SU = CIN >= 16 ? 16 : 8;
+        int ci = tid / HW, p = tid - ci * HW;                  // element e = tid + 512 k  ->  (ci, p), advanced without dividing
+        for (int e0 = tid; e0 < CIN * HW; e0 += 512 * SU) {
+            float v[SU];
+            int dst[SU];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int cu = ci < CIN ? ci : CIN - 1, t = tab[r], p = t & 0xFFF;
-                const bool in = p != 0xFFF;
-                if (DGRAD && bn.y) {
-                    const size_t pe = ((size_t)b * CIN + cu) * npc + ((t >> 28) < 4 ? (t >> 12) & 0xFFFF : 0);
-                    v[u] = bn.y[((size_t)b * CIN + cu) * HW + (in ? p : 0)];
-                    dv[u] = bn.dp[pe];
-                    kk[u] = !in ? -2 : ((int)bn.idx[pe] == (t >> 28)) ? 1 : 0;      // -2 halo, 1 this position took the pooled gradient
-                } else {
-                    const float xv = x[((size_t)b * CIN + cu) * HW + (in ? p : 0)];
-                    v[u] = in ? xv : 0.f;
-                }
-                cc[u] = cu;
-                r += 512;
-                while (r >= XP) { r -= XP; ++ci; }
+            for (int u = 0; u < SU; ++u) {
+                const int cu = ci < CIN ? ci : CIN - 1;
+                v[u] = x[((size_t)b * CIN + cu) * HW + p];
+                dst[u] = cu * XP + pos[p];
+                p += 512;
+                while (p >= HW) { p -= HW; ++ci; }
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (e0 + u * 512 < CIN * XP) {
-                    if (DGRAD && bn.y) {
-                        const f32x4 c4 = *reinterpret_cast<const f32x4*>(cst + cc[u] * 4);
-                        xs[e0 + u * 512] = kk[u] == -2 ? 0.f : c4[0] * ((kk[u] == 1 ? dv[u] : 0.f) - c4[1] - (v[u] - c4[2]) * c4[3]);
-                    } else xs[e0 + u * 512] = v[u];
-                }
+            for (int u = 0; u < SU; ++u)
+                if (e0 + u * 512 < CIN * HW) xs[dst[u]] = v[u];
         }
     }
     // K order.  CIN % 4 == 0 (conv2): k = tap * CIN + ci, so the k-step s = k / 4 of lane quarter q is channel 4 (s % (CIN/4)) + q at tap
@@ -242,7 +218,7 @@ __global__ void __launch_bounds__(512, 4) conv3x3_fwd_mfma_kernel(const float* _
     // Two position tiles per trip (two independent accumulator chains per output-channel tile), their B values read from LDS in blocks
     // of KB k-steps BEFORE the block's MFMAs: written as read-one / multiply-one the compiler waited out the LDS latency in front of
     // every MFMA (matrix pipe 19 % busy, 40 us for conv2 at B = 512).
-    constexpr int KB = KS < 12 ? KS : 12, NTI = 2;
+    constexpr int KB = KS < 12 ? KS : (KS > 40 ? 8 : 12), NTI = 2;      // (KS > 40: the A values of a block are fetched with it)
     const int stride_t = NWV / MG;
     for (int nt0 = wave / MG; nt0 < ntiles; nt0 += NTI * stride_t) {
         const float* xb[NTI];
@@ -261,6 +237,7 @@ __global__ void __launch_bounds__(512, 4) conv3x3_fwd_mfma_kernel(const float* _
         for (int s0 = 0; s0 < KS; s0 += KB) {
             float bv[NTI][KB], av[MTW][KB];
             if constexpr (ASTREAM) {
+                __builtin_amdgcn_sched_barrier(0);      // keep the blocks apart: hoisted to the top, the 72 A loads spill
 #pragma unroll
                 for (int u = 0; u < KB; ++u)
 #pragma unroll
@@ -1281,19 +1258,19 @@ int opt_in_lds(K kern, size_t lds) {
 }  // namespace
 
 // =================================================================================================== launchers
-// LDS bytes of conv3x3_fwd_mfma_kernel: halo'd window | statistics rows | halo geometry table | (DGRAD) channel constants
+// LDS bytes of conv3x3_fwd_mfma_kernel: halo'd window | statistics rows | position -> halo'd offset table
 static size_t conv_mfma_lds(int cin, int cout, int H, int W) {
     const size_t XP = (size_t)(H + 2) * (W + 2);
-    return sizeof(float) * (((cin * XP + 3) & ~(size_t)3) + 8 * (size_t)cout * 2 + ((XP + 3) & ~(size_t)3) + 4 * (size_t)cin);
+    return sizeof(float) * (((cin * XP + 3) & ~(size_t)3) + 8 * (size_t)cout * 2 + (((size_t)H * W + 3) & ~(size_t)3));
 }
 template <int CIN, int COUT>
 int conv_fwd_mfma(int B, int H, int W, const float* x, const float* w, const float* bias, float* y, float* part, hipStream_t s) {
     const size_t lds = conv_mfma_lds(CIN, COUT, H, W);
     int rc;
     if (part) { if ((rc = opt_in_lds(conv3x3_fwd_mfma_kernel<CIN, COUT, true>, lds))) return rc;
-                SHM_LAUNCH((conv3x3_fwd_mfma_kernel<CIN, COUT, true>), dim3(B), dim3(512), lds, s, x, w, bias, y, part, H, W, BnGrad{}); }
+                SHM_LAUNCH((conv3x3_fwd_mfma_kernel<CIN, COUT, true>), dim3(B), dim3(512), lds, s, x, w, bias, y, part, H, W); }
     else { if ((rc = opt_in_lds(conv3x3_fwd_mfma_kernel<CIN, COUT, false>, lds))) return rc;
-           SHM_LAUNCH((conv3x3_fwd_mfma_kernel<CIN, COUT, false>), dim3(B), dim3(512), lds, s, x, w, bias, y, part, H, W, BnGrad{}); }
+           SHM_LAUNCH((conv3x3_fwd_mfma_kernel<CIN, COUT, false>), dim3(B), dim3(512), lds, s, x, w, bias, y, part, H, W); }
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
@@ -1416,11 +1393,11 @@ int cnn_bn_bwd_apply(int B, int C, int H, int W, const BnGrad& g, float* dy, hip
 int cnn_conv_bwd_data2(int B, int H, int W, const float* dy, const BnGrad* fuse, const float* w, float* dx, hipStream_t s) {
     const size_t lds = sizeof(float) * ((size_t)32 * H * W + 32 * 9 * 16);
     int rc;
-    // matrix-pipe form (the forward kernel on transposed / flipped weights, dy formed while staging) when the halo'd window fits
+    // matrix-pipe form (the forward kernel on transposed / flipped weights) when dy exists in memory and the halo'd window fits
     const size_t lds_m = conv_mfma_lds(32, 16, H, W);
-    if (lds_m <= 150 * 1024 && !getenv("SHM_CNN_VALU_DGRAD")) {
+    if (!fuse && lds_m <= 150 * 1024 && !getenv("SHM_CNN_VALU_DGRAD")) {
         if ((rc = opt_in_lds(conv3x3_fwd_mfma_kernel<32, 16, false, true>, lds_m))) return rc;
-        SHM_LAUNCH((conv3x3_fwd_mfma_kernel<32, 16, false, true>), dim3(B), dim3(512), lds_m, s, dy, w, nullptr, dx, nullptr, H, W, fuse ? *fuse : BnGrad{});
+        SHM_LAUNCH((conv3x3_fwd_mfma_kernel<32, 16, false, true>), dim3(B), dim3(512), lds_m, s, dy, w, nullptr, dx, nullptr, H, W);
         SHM_LAUNCH_CHECK();
         return SHM_OK;
     }
