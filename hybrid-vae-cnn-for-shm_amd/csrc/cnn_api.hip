@@ -17,11 +17,12 @@ struct shm_cnn_plan {
     // parameter element offsets (flat buffer)
     int64_t c1w, c1b, g1, b1, c2w, c2b, g2, b2, f1w, f1b, f2w, f2b, n_params;
     // workspace byte offsets
+    size_t xh1, xh2;                 // training plans: normalised conv output at the pooled cells' argmax (BatchNorm-backward statistics)
     size_t y1, p1, i1, y2, p2, i2, z1, a1, logits, dlogits, da1, dz1, dflat, dy2, dp1, dy1;
     size_t part1, part2, mean1, rstd1, scale1, shift1, mean2, rstd2, scale2, shift2, k1, k2, wpart, wpart1, gemm_partial, gemm_partial2, colsum_scratch, colsum_scratch2;
     size_t gemm_partial_elems;
     size_t ws_bytes;
-    bool fwd_saved, loss_done;
+    bool fwd_saved, loss_done, xh_saved;
     uint64_t drop_seed;
     float drop_p_used;
 };
@@ -110,6 +111,7 @@ extern "C" int shm_cnn_plan_create(const shm_cnn_config* cfg, int32_t B, int32_t
     p->mean1 = take(4 * C1); p->rstd1 = take(4 * C1); p->scale1 = take(4 * C1); p->shift1 = take(4 * C1);
     p->mean2 = take(4 * C2); p->rstd2 = take(4 * C2); p->scale2 = take(4 * C2); p->shift2 = take(4 * C2);
     if (training) {
+        p->xh1 = take(4 * n_p1); p->xh2 = take(4 * n_p2);
         p->dlogits = take(4 * Bz * NC); p->da1 = take(4 * Bz * FC1); p->dz1 = take(4 * Bz * FC1);
         p->dflat = take(4 * n_p2); p->dy2 = take(4 * n_y2); p->dp1 = take(4 * n_p1); p->dy1 = take(4 * n_y1);
         p->k1 = take(4 * C2); p->k2 = take(4 * C2);
@@ -143,6 +145,8 @@ extern "C" int shm_cnn_forward(shm_cnn_plan* p, const float* params, float* runn
     p->fwd_saved = false; p->loss_done = false;
     float* y1 = at<float>(ws, p->y1); float* p1 = at<float>(ws, p->p1);
     float* y2 = at<float>(ws, p->y2); float* p2 = at<float>(ws, p->p2);
+    const bool keep_xh = train && p->training && !getenv("SHM_CNN_NO_XHAT");      // the backward's statistics pass then never touches y1 / y2
+    p->xh_saved = keep_xh;
     // block 1
     { KernelTimer kt("cnn.conv1_fwd", (hipStream_t)stream);
     if ((rc = cnn_conv_fwd(1, B, p->H0, p->W0, x, params + p->c1w, params + p->c1b, y1, train ? at<float>(ws, p->part1) : nullptr, s))) return rc;
@@ -152,7 +156,8 @@ extern "C" int shm_cnn_forward(shm_cnn_plan* p, const float* params, float* runn
                               running + 16, at<float>(ws, p->mean1), at<float>(ws, p->rstd1), at<float>(ws, p->scale1), at<float>(ws, p->shift1), s))) return rc;
     }
     { KernelTimer kt("cnn.bn1_pool", (hipStream_t)stream);
-    if ((rc = cnn_bn_relu_pool(B, C1, p->H0, p->W0, y1, at<float>(ws, p->scale1), at<float>(ws, p->shift1), p1, at<unsigned char>(ws, p->i1), s))) return rc;
+    if ((rc = cnn_bn_relu_pool(B, C1, p->H0, p->W0, y1, at<float>(ws, p->scale1), at<float>(ws, p->shift1), p1, at<unsigned char>(ws, p->i1), s,
+                               at<float>(ws, p->mean1), at<float>(ws, p->rstd1), keep_xh ? at<float>(ws, p->xh1) : nullptr))) return rc;
     }
     // block 2
     { KernelTimer kt("cnn.conv2_fwd", (hipStream_t)stream);
@@ -163,7 +168,8 @@ extern "C" int shm_cnn_forward(shm_cnn_plan* p, const float* params, float* runn
                               running + 64, at<float>(ws, p->mean2), at<float>(ws, p->rstd2), at<float>(ws, p->scale2), at<float>(ws, p->shift2), s))) return rc;
     }
     { KernelTimer kt("cnn.bn2_pool", (hipStream_t)stream);
-    if ((rc = cnn_bn_relu_pool(B, C2, p->H1, p->W1, y2, at<float>(ws, p->scale2), at<float>(ws, p->shift2), p2, at<unsigned char>(ws, p->i2), s))) return rc;
+    if ((rc = cnn_bn_relu_pool(B, C2, p->H1, p->W1, y2, at<float>(ws, p->scale2), at<float>(ws, p->shift2), p2, at<unsigned char>(ws, p->i2), s,
+                               at<float>(ws, p->mean2), at<float>(ws, p->rstd2), keep_xh ? at<float>(ws, p->xh2) : nullptr))) return rc;
     }
     // dense head (flatten is a no-op on the NCHW pooled tensor)
     const float dp = train ? p->cfg.dropout : 0.f;
@@ -247,7 +253,7 @@ extern "C" int shm_cnn_backward(shm_cnn_plan* p, const float* params, const floa
     const bool dy2_left = fuse2 && cnn_conv_bwd_weight_leaves_dy(2, p->H1, p->W1, g2.y);
     { KernelTimer kt("cnn.bn2_bwd", (hipStream_t)stream);
     if ((rc = cnn_bn_bwd_stats(B, C2, p->H1, p->W1, g2.dp, g2.idx, g2.y, g2.mean, g2.rstd, at<float>(ws, p->part2), at<float>(ws, p->k1), at<float>(ws, p->k2),
-                               grads + p->g2, grads + p->b2, s))) return rc;
+                               grads + p->g2, grads + p->b2, s, p->xh_saved ? at<float>(ws, p->xh2) : nullptr))) return rc;
     if (!fuse2 && (rc = cnn_bn_bwd_apply(B, C2, p->H1, p->W1, g2, at<float>(ws, p->dy2), s))) return rc;
     }
     { KernelTimer kt("cnn.conv2_dw", (hipStream_t)stream);
@@ -269,7 +275,7 @@ extern "C" int shm_cnn_backward(shm_cnn_plan* p, const float* params, const floa
     const bool fuse1 = cnn_conv_bwd_weight_fusable(1, p->H0, p->W0, g1.y);
     { KernelTimer kt("cnn.bn1_bwd", (hipStream_t)stream);
     if ((rc = cnn_bn_bwd_stats(B, C1, p->H0, p->W0, g1.dp, g1.idx, g1.y, g1.mean, g1.rstd, at<float>(ws, p->part1), at<float>(ws, p->k1), at<float>(ws, p->k2),
-                               grads + p->g1, grads + p->b1, s))) return rc;
+                               grads + p->g1, grads + p->b1, s, p->xh_saved ? at<float>(ws, p->xh1) : nullptr))) return rc;
     if (!fuse1 && (rc = cnn_bn_bwd_apply(B, C1, p->H0, p->W0, g1, at<float>(ws, p->dy1), s))) return rc;
     }
     float* wpart1 = at<float>(ws, p->wpart1);

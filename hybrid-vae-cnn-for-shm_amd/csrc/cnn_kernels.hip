@@ -333,23 +333,28 @@ __global__ void __launch_bounds__(64) bn_finalize_kernel(int C, int B, long long
 
 // ------------------------------------------------------------------------------------------------ BN + ReLU + MaxPool2
 // grid = B.  idx: 0..3 = position (kh*2+kw) of the first maximum of the ReLU'd 2x2 cell, 4 = cell is dead (max <= 0)
+// xh (training): the normalised conv output (y - mean) rstd AT the argmax of every live cell — all the BatchNorm-backward statistics
+// pass needs of y, so that pass reads a pooled-size tensor instead of gathering through the full-size one.
 __global__ void __launch_bounds__(256) bn_relu_pool_kernel(int C, int H, int W, const float* __restrict__ y,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
-                                                           float* __restrict__ out, unsigned char* __restrict__ idx) {
+                                                           float* __restrict__ out, unsigned char* __restrict__ idx,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ xh) {
     const int Hp = H / 2, Wp = W / 2, b = blockIdx.x;
     const int n = C * Hp * Wp;
     for (int e = threadIdx.x; e < n; e += 256) {
         const int c = e / (Hp * Wp), r = e - c * Hp * Wp, hp = r / Wp, wp = r - hp * Wp;
         const float* yp = y + ((size_t)b * C + c) * H * W + (size_t)(2 * hp) * W + 2 * wp;
         const float sc = scale[c], sh = shift[c];
-        float best = fmaxf(fmaf(yp[0], sc, sh), 0.f);
+        const float y0 = yp[0], y1 = yp[1], y2 = yp[W], y3 = yp[W + 1];
+        float best = fmaxf(fmaf(y0, sc, sh), 0.f), yb = y0;
         int bi = 0;
-        const float v1 = fmaxf(fmaf(yp[1], sc, sh), 0.f), v2 = fmaxf(fmaf(yp[W], sc, sh), 0.f), v3 = fmaxf(fmaf(yp[W + 1], sc, sh), 0.f);
-        if (v1 > best) { best = v1; bi = 1; }
-        if (v2 > best) { best = v2; bi = 2; }
-        if (v3 > best) { best = v3; bi = 3; }
+        const float v1 = fmaxf(fmaf(y1, sc, sh), 0.f), v2 = fmaxf(fmaf(y2, sc, sh), 0.f), v3 = fmaxf(fmaf(y3, sc, sh), 0.f);
+        if (v1 > best) { best = v1; bi = 1; yb = y1; }
+        if (v2 > best) { best = v2; bi = 2; yb = y2; }
+        if (v3 > best) { best = v3; bi = 3; yb = y3; }
         out[(size_t)b * n + e] = best;
         if (idx) idx[(size_t)b * n + e] = best > 0.f ? (unsigned char)bi : (unsigned char)4;
+        if (xh) xh[(size_t)b * n + e] = (yb - mean[c]) * rstd[c];
     }
 }
 
@@ -684,7 +689,7 @@ __global__ void __launch_bounds__(256) build_input_kernel(int B, int TD, const f
 // A wave per channel (channels w, w + 4, ...): wave-level sums only — the block-wide form paid two barriers per channel and sum.
 __global__ void __launch_bounds__(256) bn_bwd_stats_kernel(int C, int H, int W, const float* __restrict__ dp, const unsigned char* __restrict__ idx,
                                                            const float* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                           float* __restrict__ part) {
+                                                           float* __restrict__ part, const float* __restrict__ xh) {
     const int Hp = H / 2, Wp = W / 2, b = blockIdx.x, npc = Hp * Wp, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int c = wv; c < C; c += 4) {
         float s1 = 0.f, s2 = 0.f;
@@ -693,10 +698,14 @@ __global__ void __launch_bounds__(256) bn_bwd_stats_kernel(int C, int H, int W, 
             const size_t e = ((size_t)b * C + c) * npc + r;
             const int k = idx[e];
             if (k < 4) {
-                const int hp = r / Wp, wp = r - hp * Wp;
-                const float yv = y[((size_t)b * C + c) * H * W + (size_t)(2 * hp + (k >> 1)) * W + 2 * wp + (k & 1)];
+                float xv;
+                if (xh) xv = xh[e];                                   // saved by the forward's pooling pass
+                else {
+                    const int hp = r / Wp, wp = r - hp * Wp;
+                    xv = (y[((size_t)b * C + c) * H * W + (size_t)(2 * hp + (k >> 1)) * W + 2 * wp + (k & 1)] - m) * rs;
+                }
                 const float g = dp[e];
-                s1 += g; s2 = fmaf(g, (yv - m) * rs, s2);
+                s1 += g; s2 = fmaf(g, xv, s2);
             }
         }
         s1 = wave_sum(s1); s2 = wave_sum(s2);
@@ -1306,8 +1315,9 @@ int cnn_bn_finalize(int C, int B, long long n, int train, const float* part, con
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
-int cnn_bn_relu_pool(int B, int C, int H, int W, const float* y, const float* scale, const float* shift, float* out, unsigned char* idx, hipStream_t s) {
-    SHM_LAUNCH(bn_relu_pool_kernel, dim3(B), dim3(256), 0, s, C, H, W, y, scale, shift, out, idx);
+int cnn_bn_relu_pool(int B, int C, int H, int W, const float* y, const float* scale, const float* shift, float* out, unsigned char* idx, hipStream_t s,
+                     const float* mean, const float* rstd, float* xh) {
+    SHM_LAUNCH(bn_relu_pool_kernel, dim3(B), dim3(256), 0, s, C, H, W, y, scale, shift, out, idx, mean, rstd, xh);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
@@ -1378,8 +1388,8 @@ int cnn_build_input(int B, int TD, const float* z, const float* zhat, float* xin
     return SHM_OK;
 }
 int cnn_bn_bwd_stats(int B, int C, int H, int W, const float* dp, const unsigned char* idx, const float* y, const float* mean, const float* rstd,
-                     float* part, float* k1, float* k2, float* dgamma, float* dbeta, hipStream_t s) {
-    SHM_LAUNCH(bn_bwd_stats_kernel, dim3(B), dim3(256), 0, s, C, H, W, dp, idx, y, mean, rstd, part);
+                     float* part, float* k1, float* k2, float* dgamma, float* dbeta, hipStream_t s, const float* xh) {
+    SHM_LAUNCH(bn_bwd_stats_kernel, dim3(B), dim3(256), 0, s, C, H, W, dp, idx, y, mean, rstd, part, xh);
     SHM_LAUNCH_CHECK();
     SHM_LAUNCH(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, C, B, (long long)B * H * W, part, k1, k2, dgamma, dbeta);
     SHM_LAUNCH_CHECK();

@@ -9,7 +9,9 @@ namespace shm {
 int cnn_conv_fwd(int layer, int B, int H, int W, const float* x, const float* w, const float* bias, float* y, float* part, hipStream_t s);
 int cnn_bn_finalize(int C, int B, long long n_per_channel, int train, const float* part, const float* gamma, const float* beta,
                     float* run_mean, float* run_var, float* mean, float* rstd, float* scale, float* shift, hipStream_t s);
-int cnn_bn_relu_pool(int B, int C, int H, int W, const float* y, const float* scale, const float* shift, float* out, unsigned char* idx, hipStream_t s);
+// xh != nullptr (with mean / rstd): also keep the normalised conv output at every cell's argmax (for cnn_bn_bwd_stats)
+int cnn_bn_relu_pool(int B, int C, int H, int W, const float* y, const float* scale, const float* shift, float* out, unsigned char* idx, hipStream_t s,
+                     const float* mean = nullptr, const float* rstd = nullptr, float* xh = nullptr);
 int cnn_linear_fwd(int B, int F, int O, const float* in, const float* Wt, const float* bias, float* pre, float* out, int relu, float drop_p,
                    uint64_t seed, hipStream_t s);
 int cnn_linear_bwd_dx(int B, int F, int O, const float* dy, const float* Wt, const float* pre, float* dx, float drop_p, uint64_t seed, hipStream_t s);
@@ -29,7 +31,7 @@ int cnn_build_input(int B, int TD, const float* z, const float* zhat, float* xin
 // kernels from the operands in BnGrad, so dy never exists in memory.
 struct BnGrad { const float* y; const float* dp; const unsigned char* idx; const float* mean; const float* rstd; const float* gamma; const float* k1; const float* k2; };
 int cnn_bn_bwd_stats(int B, int C, int H, int W, const float* dp, const unsigned char* idx, const float* y, const float* mean, const float* rstd,
-                     float* part, float* k1, float* k2, float* dgamma, float* dbeta, hipStream_t s);
+                     float* part, float* k1, float* k2, float* dgamma, float* dbeta, hipStream_t s, const float* xh = nullptr);
 int cnn_bn_bwd_apply(int B, int C, int H, int W, const BnGrad& g, float* dy, hipStream_t s);
 int cnn_conv_bwd_data2(int B, int H, int W, const float* dy, const BnGrad* fuse, const float* w, float* dx, hipStream_t s);
 bool cnn_conv_bwd_weight_fusable(int layer, int H, int W, const float* y);
