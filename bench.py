@@ -65,7 +65,8 @@ def kernel_alg_flops(name, B, path="fp32"):
     return 0
 
 
-PMC_SUMMARIES = {"bf16": ROOT / "profiles" / "r02_bf16_pmc_traffic.json", "split": ROOT / "profiles" / "r02_split_pmc_traffic.json"}
+PMC_SUMMARIES = {"bf16": ROOT / "profiles" / "r02_bf16_pmc_traffic.json", "split": ROOT / "profiles" / "r02_split_pmc_traffic.json",
+                 "cnn": ROOT / "profiles" / "r02_cnn_pmc_traffic.json"}
 
 # substrings of the demangled kernel names in the PMC summaries, per profile label
 PMC_KERNELS = {
@@ -75,6 +76,10 @@ PMC_KERNELS = {
              "lstm_bwd": {"enc": "lstm_bwd_pair_bf16_kernel<128, 0", "dec": "lstm_bwd_pair_bf16_kernel<128, 2",
                           "enc0": "lstm_bwd_bf16_kernel<128, 1>", "dec0": "lstm_bwd_bf16_kernel<128, 1>",
                           "enc1": "lstm_bwd_bf16_kernel<128, 0>", "dec1": "lstm_bwd_bf16_kernel<128, 2>"}},
+    "cnn": {"cnn": {"conv1_fwd": "conv3x3_fwd_mfma_kernel<2, 16, true, false>", "conv2_fwd": "conv3x3_fwd_mfma_kernel<16, 32, true, false>",
+                    "conv2_dx": "conv3x3_fwd_mfma_kernel<32, 16, false, true>", "conv2_dw": "conv3x3_bwd_weight_ksplit_kernel<16, 32>",
+                    "conv1_dw": "conv3x3_bwd_weight_mfma_kernel<2, 16, true>", "fc1_dw": "dense_dw_mfma_kernel<8>",
+                    "fc1_fwd": "linear_fwd_mfma_kernel", "fc1_dx": "linear_bwd_dx_mfma_kernel"}},
     "split": {"lstm_fwd": {"enc0": "lstm_fwd_sp_kernel<128, 2, true>", "enc1": "lstm_fwd_sp_kernel<128, 0, true>",
                            "dec0": "lstm_fwd_sp_kernel<128, 1, true>", "dec1": "lstm_fwd_sp_kernel<128, 0, true>"},
               "lstm_bwd": {"enc0": "lstm_bwd_sp_kernel<128, 1>", "dec0": "lstm_bwd_sp_kernel<128, 1>",
@@ -226,8 +231,9 @@ def cnn_measure(steps, warmup, profile_steps, with_cpu_baseline):
         dom = max((k for k in per if cnn_alg_flops(k, B_PER_GPU) > 0), key=lambda k: per[k])
         fl = cnn_alg_flops(dom, B_PER_GPU)
         ach = fl / (per[dom] * 1e-3) / 1e12
+        traffic, why = pmc_traffic_checked(dom, "cnn")
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": PEAK_TFLOPS["f32"], "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS["f32"], 5),
-                "traffic": None, "traffic_note": "no PMC pass committed for the CNN line", "avg_launch_ms": round(per[dom], 4), "alg_flops_per_launch": fl,
+                "traffic": traffic, "traffic_note": why, "avg_launch_ms": round(per[dom], 4), "alg_flops_per_launch": fl,
                 "launch_groups_per_step": len(per), "kernels_ms": {k: round(v, 4) for k, v in sorted(per.items())}}
     m.eval()
     with torch.no_grad():
