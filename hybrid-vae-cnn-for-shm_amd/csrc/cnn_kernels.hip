@@ -299,6 +299,23 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
+// (sum, sum of squares) of channel c over the B per-window partial pairs, as one lane's share: windows lane, lane + 64, ... added in
+// that order in fp64 (the caller finishes with a butterfly).  The pairs are fetched as 8-byte loads, eight in flight: written as one
+// dependent load pair per trip, this loop's latency was most of the 5 us the finalize launches take.
+__device__ __forceinline__ void partial_pair_sums(const float* __restrict__ part, int C, int c, int B, int lane, double& s, double& q) {
+    s = 0.0; q = 0.0;
+    for (int b0 = lane; b0 < B; b0 += 64 * 8) {
+        f32x2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int b = b0 + u * 64;
+            v[u] = *reinterpret_cast<const f32x2*>(part + ((size_t)(b < B ? b : lane) * C + c) * 2);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (b0 + u * 64 < B) { s += (double)v[u][0]; q += (double)v[u][1]; }
+    }
+}
 // grid = C, one wave per channel: lanes stride over the B per-window partials (fp64), then a butterfly — fixed order.
 // train: batch mean / biased var, running statistics updated with momentum 0.1 and the unbiased variance; eval: running statistics.
 // (One thread per channel walking all B partials serially took 126 us per launch at B = 512.)
@@ -309,9 +326,10 @@ __global__ void __launch_bounds__(64) bn_finalize_kernel(int C, int B, long long
                                                          float* __restrict__ scale, float* __restrict__ shift) {
     const int c = blockIdx.x;
     float mean, var;
+    const float rm0 = run_mean[c], rv0 = run_var[c], gm = gamma[c], bt = beta[c];      // issued beside the partial loads, not behind the reduction
     if (train) {
-        double s = 0.0, q = 0.0;
-        for (int b = threadIdx.x; b < B; b += 64) { s += (double)part[((size_t)b * C + c) * 2]; q += (double)part[((size_t)b * C + c) * 2 + 1]; }
+        double s, q;
+        partial_pair_sums(part, C, c, B, threadIdx.x, s, q);
         s = wave_sum_f64(s); q = wave_sum_f64(q);
         if (threadIdx.x != 0) return;
         const double m = s / (double)n_per_channel;
@@ -319,16 +337,16 @@ __global__ void __launch_bounds__(64) bn_finalize_kernel(int C, int B, long long
         if (v < 0.0) v = 0.0;
         mean = (float)m; var = (float)v;
         const double unb = n_per_channel > 1 ? v * (double)n_per_channel / (double)(n_per_channel - 1) : v;
-        run_mean[c] = 0.9f * run_mean[c] + 0.1f * mean;
-        run_var[c] = 0.9f * run_var[c] + 0.1f * (float)unb;
+        run_mean[c] = 0.9f * rm0 + 0.1f * mean;
+        run_var[c] = 0.9f * rv0 + 0.1f * (float)unb;
     } else {
         if (threadIdx.x != 0) return;
-        mean = run_mean[c]; var = run_var[c];
+        mean = rm0; var = rv0;
     }
     const float rstd = 1.0f / sqrtf(var + 1e-5f);
     mean_out[c] = mean; rstd_out[c] = rstd;
-    scale[c] = gamma[c] * rstd;
-    shift[c] = beta[c] - mean * gamma[c] * rstd;
+    scale[c] = gm * rstd;
+    shift[c] = bt - mean * gm * rstd;
 }
 
 // ------------------------------------------------------------------------------------------------ BN + ReLU + MaxPool2
@@ -716,8 +734,8 @@ __global__ void __launch_bounds__(64) bn_bwd_finalize_kernel(int C, int B, long 
                                                              float* __restrict__ k1, float* __restrict__ k2, float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta) {
     const int c = blockIdx.x;                                  // one wave per channel (see bn_finalize_kernel)
-    double s = 0.0, q = 0.0;
-    for (int b = threadIdx.x; b < B; b += 64) { s += (double)part[((size_t)b * C + c) * 2]; q += (double)part[((size_t)b * C + c) * 2 + 1]; }
+    double s, q;
+    partial_pair_sums(part, C, c, B, threadIdx.x, s, q);
     s = wave_sum_f64(s); q = wave_sum_f64(q);
     if (threadIdx.x != 0) return;
     dbeta[c] = (float)s; dgamma[c] = (float)q;
