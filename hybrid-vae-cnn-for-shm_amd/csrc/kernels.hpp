@@ -102,6 +102,7 @@ struct ReduceJob {
     const float* partial; int nparts; unsigned n_out; size_t stride;   // out[i] = sum_p partial[p*stride + i], fixed order
     float* out0; float* out1;                                          // out1 optional (same values)
     int tr_M;                                                          // > 0: element i = n*tr_M + m is written to out0[m*(n_out/tr_M) + n]
+    int vec;                                                           // set by launch_reduce_batch: 16-byte loads, 128 outputs per block
 };
 constexpr int MAX_REDUCE_JOBS = 12;
 struct ReduceJobs { ReduceJob job[MAX_REDUCE_JOBS]; int first_block[MAX_REDUCE_JOBS + 1]; int n; };

@@ -512,6 +512,34 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __res
     }
 }
 
+// the same reduction with 16 bytes per lane (128 outputs per block; a partial row is read in 512-byte runs): same chains, same order per
+// output, so the result is bit-identical to reduce_partials_kernel.  Requires n_out, n multiples of 4 and 16-byte aligned pointers.
+__global__ void __launch_bounds__(256) reduce_partials_v4_kernel(const float* __restrict__ partial, int nparts, size_t n_out, size_t n,
+                                                                 float* __restrict__ out0, float* __restrict__ out1, float* __restrict__ outB) {
+    __shared__ f32x4 red4[8][32];
+    if (blockIdx.y == 1) { partial += n_out; out0 = outB; out1 = nullptr; }     // second product of a shared-A GEMM
+    const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const size_t i4 = ((size_t)blockIdx.x * 32 + o) * 4;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 s0 = z4, s1 = z4, s2 = z4, s3 = z4, s4 = z4, s5 = z4, s6 = z4, s7 = z4;
+    if (i4 < n_out) {
+        auto ld = [&](int p) { return *reinterpret_cast<const f32x4*>(partial + (size_t)p * n + i4); };
+        int p = grp;
+        for (; p + 56 < nparts; p += 64) {
+            s0 += ld(p); s1 += ld(p + 8); s2 += ld(p + 16); s3 += ld(p + 24);
+            s4 += ld(p + 32); s5 += ld(p + 40); s6 += ld(p + 48); s7 += ld(p + 56);
+        }
+        for (; p < nparts; p += 8) s0 += ld(p);
+    }
+    red4[grp][o] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+    __syncthreads();
+    if (grp == 0 && i4 < n_out) {
+        const f32x4 v = ((red4[0][o] + red4[1][o]) + (red4[2][o] + red4[3][o])) + ((red4[4][o] + red4[5][o]) + (red4[6][o] + red4[7][o]));
+        *reinterpret_cast<f32x4*>(out0 + i4) = v;
+        if (out1) *reinterpret_cast<f32x4*>(out1 + i4) = v;
+    }
+}
+
 // every deferred reduction of a backward stage in one launch: block -> (job, 32 outputs) through the prefix table
 __global__ void __launch_bounds__(256) reduce_batch_kernel(ReduceJobs jobs) {
     __shared__ float red[8][32];
@@ -519,9 +547,34 @@ __global__ void __launch_bounds__(256) reduce_batch_kernel(ReduceJobs jobs) {
     while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.first_block[j + 1]) ++j;
     const ReduceJob jb = jobs.job[j];
     const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const size_t i = (size_t)(blockIdx.x - jobs.first_block[j]) * 32 + o;
     const float* __restrict__ partial = jb.partial;
     const size_t n = jb.stride;
+    if (jb.vec) {
+        // 16 bytes per lane: a block covers 128 outputs, a partial row is read in 512-byte runs (the 4-byte form streamed the 67 MB of a
+        // split-K GEMM's partials at 3.9 TB/s); same summation order per output as below
+        __shared__ f32x4 red4[8][32];
+        const size_t i4 = ((size_t)(blockIdx.x - jobs.first_block[j]) * 32 + o) * 4;
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 s0 = z4, s1 = z4, s2 = z4, s3 = z4, s4 = z4, s5 = z4, s6 = z4, s7 = z4;
+        if (i4 < jb.n_out) {
+            auto ld = [&](int p) { return *reinterpret_cast<const f32x4*>(partial + (size_t)p * n + i4); };
+            int p = grp;
+            for (; p + 56 < jb.nparts; p += 64) {
+                s0 += ld(p); s1 += ld(p + 8); s2 += ld(p + 16); s3 += ld(p + 24);
+                s4 += ld(p + 32); s5 += ld(p + 40); s6 += ld(p + 48); s7 += ld(p + 56);
+            }
+            for (; p < jb.nparts; p += 8) s0 += ld(p);
+        }
+        red4[grp][o] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+        __syncthreads();
+        if (grp == 0 && i4 < jb.n_out) {
+            const f32x4 v = ((red4[0][o] + red4[1][o]) + (red4[2][o] + red4[3][o])) + ((red4[4][o] + red4[5][o]) + (red4[6][o] + red4[7][o]));
+            *reinterpret_cast<f32x4*>(jb.out0 + i4) = v;
+            if (jb.out1) *reinterpret_cast<f32x4*>(jb.out1 + i4) = v;
+        }
+        return;
+    }
+    const size_t i = (size_t)(blockIdx.x - jobs.first_block[j]) * 32 + o;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
     if (i < jb.n_out) {
         int p = grp;
@@ -815,13 +868,24 @@ int launch_vae_loss(int B, int T, int D, int Z, const float* x, const float* rec
     return SHM_OK;
 }
 size_t colsum_scratch_elems(int R, int N) { return (size_t)ceil_div(R, cs_rows(R)) * N; }
+// 16-byte form when the shapes and pointers allow it and the reduction is big enough to be a stream (bit-identical results)
+static bool reduce_v4_ok(const float* partial, size_t n_out, size_t stride, const float* a, const float* b, const float* c) {
+    const uintptr_t al = reinterpret_cast<uintptr_t>(partial) | reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c);
+    return n_out % 4 == 0 && stride % 4 == 0 && (al & 15) == 0 && n_out >= 4096 && !getenv("SHM_REDUCE_SCALAR");
+}
 int launch_reduce_partials(const float* partial, int nparts, size_t n, float* out0, float* out1, hipStream_t s) {
-    SHM_LAUNCH(reduce_partials_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, partial, nparts, n, n, out0, out1, (float*)nullptr);
+    if (reduce_v4_ok(partial, n, n, out0, out1, nullptr))
+        SHM_LAUNCH(reduce_partials_v4_kernel, dim3((unsigned)((n + 127) / 128)), dim3(256), 0, s, partial, nparts, n, n, out0, out1, (float*)nullptr);
+    else
+        SHM_LAUNCH(reduce_partials_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, partial, nparts, n, n, out0, out1, (float*)nullptr);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
 int launch_reduce_partials_strided(const float* partial, int nparts, size_t n, size_t stride, float* out0, hipStream_t s) {
-    SHM_LAUNCH(reduce_partials_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, partial, nparts, n, stride, out0, (float*)nullptr, (float*)nullptr);
+    if (reduce_v4_ok(partial, n, stride, out0, nullptr, nullptr))
+        SHM_LAUNCH(reduce_partials_v4_kernel, dim3((unsigned)((n + 127) / 128)), dim3(256), 0, s, partial, nparts, n, stride, out0, (float*)nullptr, (float*)nullptr);
+    else
+        SHM_LAUNCH(reduce_partials_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, partial, nparts, n, stride, out0, (float*)nullptr, (float*)nullptr);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
@@ -843,7 +907,13 @@ int reduce_jobs_add(ReduceJobs& j, const float* partial, int nparts, size_t n_ou
 int launch_reduce_batch(ReduceJobs& jobs, hipStream_t s) {
     if (jobs.n == 0) return SHM_OK;
     int blocks = 0;
-    for (int i = 0; i < jobs.n; ++i) { jobs.first_block[i] = blocks; blocks += (int)((jobs.job[i].n_out + 31) / 32); }
+    for (int i = 0; i < jobs.n; ++i) {
+        ReduceJob& r = jobs.job[i];
+        const uintptr_t al = reinterpret_cast<uintptr_t>(r.partial) | reinterpret_cast<uintptr_t>(r.out0) | reinterpret_cast<uintptr_t>(r.out1);
+        r.vec = (r.n_out % 4 == 0 && r.stride % 4 == 0 && (al & 15) == 0 && r.tr_M == 0 && r.n_out >= 4096 && !getenv("SHM_REDUCE_SCALAR")) ? 1 : 0;
+        jobs.first_block[i] = blocks;
+        blocks += (int)((r.n_out + (r.vec ? 127 : 31)) / (r.vec ? 128 : 32));
+    }
     jobs.first_block[jobs.n] = blocks;
     SHM_LAUNCH(reduce_batch_kernel, dim3(blocks), dim3(256), 0, s, jobs);
     SHM_LAUNCH_CHECK();
@@ -852,6 +922,9 @@ int launch_reduce_batch(ReduceJobs& jobs, hipStream_t s) {
 }
 // partial[split][2][n]: both products of a shared-A GEMM in one launch
 int launch_reduce_partials_pair(const float* partial, int nparts, size_t n, float* outA, float* outB, hipStream_t s) {
+    if (reduce_v4_ok(partial, n, 2 * n, outA, outB, nullptr))
+        SHM_LAUNCH(reduce_partials_v4_kernel, dim3((unsigned)((n + 127) / 128), 2), dim3(256), 0, s, partial, nparts, n, 2 * n, outA, (float*)nullptr, outB);
+    else
     SHM_LAUNCH(reduce_partials_kernel, dim3((unsigned)((n + 31) / 32), 2), dim3(256), 0, s, partial, nparts, n, 2 * n, outA, (float*)nullptr, outB);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
