@@ -338,6 +338,18 @@ __global__ void __launch_bounds__(64 * OUT_WAVES) out_fwd_mfma_kernel(int B, int
     const bf16x8 zero8 = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
     for (int g0 = g_lo + w * GB; g0 < g_hi; g0 += OUT_WAVES * GB) {
         bf16x8 af[GB][KS], al[SPLIT ? GB : 1][KS];
+        float xv[GB][4];                                              // the targets of this lane's outputs, fetched beside the A fragments
+#pragma unroll
+        for (int gi = 0; gi < GB; ++gi) {
+            const int tg = (g0 + gi) * 4 + q;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int b = tile * 4 + r;
+                const bool ok = x && j < D && tg < T && g0 + gi < g_hi && b < B;
+                const float v = x ? x[ok ? ((size_t)b * T + tg) * D + j : 0] : 0.f;
+                xv[gi][r] = ok ? v : 0.f;
+            }
+        }
 #pragma unroll
         for (int gi = 0; gi < GB; ++gi) {
             const int row = (g0 + gi) * 16 + j;                       // A operand row supplied by this lane
@@ -372,7 +384,7 @@ __global__ void __launch_bounds__(64 * OUT_WAVES) out_fwd_mfma_kernel(int B, int
                         const size_t o = ((size_t)b * T + t) * D + j;
                         const float rc = acc[r] + bias;
                         if (recon) recon[o] = rc;
-                        const float e = x ? x[o] - rc : 0.f;  // x == nullptr: decode-only, no score
+                        const float e = x ? xv[gi][r] - rc : 0.f;  // x == nullptr: decode-only, no score
                         if (d_recon) d_recon[o] = -e * dsc;
                         sq[r] = fmaf(e, e, sq[r]);
                     }
