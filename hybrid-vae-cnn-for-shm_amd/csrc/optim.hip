@@ -44,7 +44,8 @@ __global__ void __launch_bounds__(256) adam_kernel(int64_t n, float* __restrict_
                                                    float* __restrict__ m, float* __restrict__ v, float step_size,
                                                    float inv_sqrt_bc2, float b1, float b2, float eps, float wd,
                                                    float max_norm, float grad_scale, const float* __restrict__ partial,
-                                                   float* __restrict__ out_norm) {
+                                                   float* __restrict__ out_norm, const uint32_t* __restrict__ status_src,
+                                                   uint32_t* __restrict__ status_dst) {
     __shared__ float red[4];
     // partial == nullptr: neither clipping nor the norm itself was asked for (the sumsq launch was skipped)
     const float tot = partial ? block_sum_256(partial[threadIdx.x], red) : 0.f;     // NORM_BLOCKS == blockDim.x
@@ -52,6 +53,8 @@ __global__ void __launch_bounds__(256) adam_kernel(int64_t n, float* __restrict_
     float coef = grad_scale;
     if (max_norm > 0.f) coef *= fminf(1.0f, max_norm / (norm + 1e-6f));
     if (blockIdx.x == 0 && threadIdx.x == 0 && out_norm) *out_norm = norm;
+    // the caller's per-step status word (a plan's sticky hand-off word) rides along: no 4-byte copy launch of its own
+    if (blockIdx.x == 0 && threadIdx.x == 0 && status_dst) *status_dst = status_src ? *status_src : 0u;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const float pi = p[i];
         const float gi = g[i] * coef + wd * pi;
@@ -70,6 +73,14 @@ extern "C" size_t shm_adam_scratch_bytes(int64_t) { return sizeof(float) * shm::
 extern "C" int shm_adam_step(int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq, int32_t step,
                              float lr, float beta1, float beta2, float eps, float weight_decay, float max_norm,
                              float grad_scale, void* scratch, float* out_norm, void* stream) {
+    return shm_adam_step_status(n, params, grads, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, weight_decay, max_norm, grad_scale, scratch,
+                                out_norm, nullptr, nullptr, stream);
+}
+
+extern "C" int shm_adam_step_status(int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq, int32_t step,
+                                    float lr, float beta1, float beta2, float eps, float weight_decay, float max_norm,
+                                    float grad_scale, void* scratch, float* out_norm, const uint32_t* status_src, uint32_t* status_dst,
+                                    void* stream) {
     using namespace shm;
     SHM_REQUIRE(n > 0 && params && grads && exp_avg && exp_avg_sq && scratch, SHM_EINVAL, "shm_adam_step: null buffer or n <= 0");
     SHM_REQUIRE(step >= 1, SHM_EINVAL, "shm_adam_step: step is 1-based, got %d", step);
@@ -87,7 +98,7 @@ extern "C" int shm_adam_step(int64_t n, float* params, float* grads, float* exp_
     const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
     SHM_LAUNCH(adam_kernel, dim3(blocks), dim3(256), 0, s, n, params, grads, exp_avg, exp_avg_sq, step_size, inv_sqrt_bc2,
-                       beta1, beta2, eps, weight_decay, max_norm, grad_scale, partial, out_norm);
+                       beta1, beta2, eps, weight_decay, max_norm, grad_scale, partial, out_norm, status_src, status_dst);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }

@@ -87,6 +87,8 @@ def _load():
         "shm_adam_scratch_bytes": (C.c_size_t, [C.c_int64]),
         "shm_adam_step": (C.c_int, [C.c_int64, f32p, f32p, f32p, f32p, C.c_int32, C.c_float, C.c_float, C.c_float,
                                     C.c_float, C.c_float, C.c_float, C.c_float, vp, f32p, vp]),
+        "shm_adam_step_status": (C.c_int, [C.c_int64, f32p, f32p, f32p, f32p, C.c_int32, C.c_float, C.c_float, C.c_float,
+                                           C.c_float, C.c_float, C.c_float, C.c_float, vp, f32p, vp, vp, vp]),
         "shm_cnn_param_count": (C.c_int64, [ccfgp]),
         "shm_cnn_param_layout": (C.c_int, [ccfgp, C.POINTER(TensorDesc), C.c_int]),
         "shm_cnn_plan_create": (C.c_int, [ccfgp, C.c_int32, C.c_int32, C.POINTER(vp)]),

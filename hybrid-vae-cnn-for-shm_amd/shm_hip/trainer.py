@@ -97,17 +97,22 @@ class VAETrainer:
         eng.backward(pl, xc, self.grads)
         scale = self.comm(self.grads)
         b1, b2 = self.betas
-        check(lib.shm_adam_step(C.c_int64(eng.n_flat), _ptr(self.flat), _ptr(self.grads), _ptr(self.exp_avg),
-                                _ptr(self.exp_avg_sq), self.step_count, C.c_float(self.lr), C.c_float(b1), C.c_float(b2),
-                                C.c_float(self.eps), C.c_float(self.wd),
-                                C.c_float(self.max_norm if self.max_norm is not None else 0.0), C.c_float(scale),
-                                _ptr(self.scratch), C.c_void_p(self.stats.data_ptr() + 12), _stream()), "shm_adam_step")
+        # the plan's sticky status word rides into stats[4] with the optimiser's last launch (no 4-byte copy launch per step)
+        off = int(lib.shm_vae_plan_status_offset(pl.handle))
+        check(lib.shm_adam_step_status(C.c_int64(eng.n_flat), _ptr(self.flat), _ptr(self.grads), _ptr(self.exp_avg),
+                                       _ptr(self.exp_avg_sq), self.step_count, C.c_float(self.lr), C.c_float(b1), C.c_float(b2),
+                                       C.c_float(self.eps), C.c_float(self.wd),
+                                       C.c_float(self.max_norm if self.max_norm is not None else 0.0), C.c_float(scale),
+                                       _ptr(self.scratch), C.c_void_p(self.stats.data_ptr() + 12),
+                                       C.c_void_p(pl.ws.data_ptr() + off) if off >= 0 else None, C.c_void_p(self.stats.data_ptr() + 16),
+                                       _stream()), "shm_adam_step_status")
         eng.mark_dirty()
-        word = self.stats[4:5].view(torch.int32)
-        eng.status_word_into(pl, word)
-        self._err_host.copy_(word, non_blocking=True)
-        self._err_event = torch.cuda.Event()
-        self._err_event.record()
+        # a host copy of the word for step()'s own check: every 4th step (the word is sticky, so nothing is missed; callers that read
+        # the returned statistics see it every step anyway)
+        if self.step_count % 4 == 1:
+            self._err_host.copy_(self.stats[4:5].view(torch.int32), non_blocking=True)
+            self._err_event = torch.cuda.Event()
+            self._err_event.record()
         return self.stats
 
     def _raise_if_failed(self, wait: bool):
@@ -130,7 +135,10 @@ class VAETrainer:
             if w:
                 raise RuntimeError(f"VAETrainer: hand-off timeout in a layer-pipelined launch (status word 0x{w:x}); results are invalid")
             return
-        self._raise_if_failed(wait=True)
+        w = int(self.stats[4:5].view(torch.int32).item()) & 0xFFFFFFFF        # blocking read of the word the last step left
+        if w:
+            raise RuntimeError(f"VAETrainer: a layer-pipelined launch reported a hand-off timeout (status word 0x{w:x}); the parameters, "
+                               "optimiser state and statistics of every step since then are invalid")
 
     @torch.no_grad()
     def evaluate(self, x: torch.Tensor, kl_w: float, eps: torch.Tensor | None = None):

@@ -151,6 +151,13 @@ size_t shm_adam_scratch_bytes(int64_t n);
 int  shm_adam_step(int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
                    int32_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
                    float max_norm, float grad_scale, void* scratch, float* out_norm, void* stream);
+/* The same step; its last launch also copies one 32-bit status word: *status_dst = status_src ? *status_src : 0 (both device
+ * pointers, status_dst may be NULL).  A trainer passes workspace + shm_vae_plan_status_offset(plan) and a slot of the statistics
+ * buffer it reads back anyway: the sticky hand-off word then reaches the host every step without a copy launch of its own. */
+int  shm_adam_step_status(int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                          int32_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                          float max_norm, float grad_scale, void* scratch, float* out_norm,
+                          const uint32_t* status_src, uint32_t* status_dst, void* stream);
 
 /* ======================================================================================================
  * CNN fault classifier (reference 4DOF/Scripts/Models/cnn_model.py:14-51): Conv2d(C,16,3,p1)+BatchNorm2d+ReLU+MaxPool2d(2),
