@@ -97,6 +97,33 @@ __global__ void __launch_bounds__(256) head_fwd_kernel(int B, int H, int Z, int 
         }
     }
     __syncthreads();
+    // fc_latent_to_hidden + tanh: a lane's weight row is Z contiguous floats — 16-byte loads, both of the lane's rows in flight together
+    const bool z4 = Z % 4 == 0 && Z <= ZMAX && (reinterpret_cast<uintptr_t>(p.l2h_w) & 15) == 0;
+    if (z4) {
+        f32x4 wv[HMAX / 64][ZMAX / 4];
+        float bb[HMAX / 64];
+#pragma unroll
+        for (int i = 0; i < HMAX / 64; ++i) {
+            const int k = lane + 64 * i, kc = k < H ? k : 0;
+            bb[i] = p.l2h_b[kc];
+#pragma unroll
+            for (int z = 0; z < ZMAX / 4; ++z)
+                if (4 * z < Z) wv[i][z] = *reinterpret_cast<const f32x4*>(p.l2h_w + (size_t)kc * Z + 4 * z);
+        }
+#pragma unroll
+        for (int i = 0; i < HMAX / 64; ++i) {
+            const int k = lane + 64 * i;
+            float acc = bb[i];
+#pragma unroll
+            for (int z = 0; z < ZMAX / 4; ++z)
+                if (4 * z < Z) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = fmaf(zs[w][4 * z + e], wv[i][z][e], acc);
+                }
+            if (valid && k < H) hb.h0[(size_t)row * H + k] = tanhf(acc);
+        }
+        return;
+    }
     for (int k = lane; k < H; k += 64) {
         float acc = p.l2h_b[k];
         const float* wr = p.l2h_w + (size_t)k * Z;
@@ -166,9 +193,28 @@ __global__ void __launch_bounds__(64 * HB_WAVES) head_bwd_kernel(int B, int H, i
         if (valid) { hb.dh0[(size_t)row * H + k] = acc; hb.dpre_l2h[(size_t)row * H + k] = dp; }
     }
     __builtin_amdgcn_wave_barrier();          // dl[w] / dmz[w] are private to wave w: LDS operations of one wave execute in order
+    // dz = dl . W_l2h: lane (zq, kq) takes quarter kq of the H rows for latent zq when 4 Z <= 64 (H / 4 scalar loads per lane, issued
+    // as one unrolled block; the one-lane-per-latent form was H dependent-latency loads), quarters combined by shuffles in a fixed order
+    float dz_q = 0.f;
+    const bool quart = 4 * Z <= 64 && H % 4 == 0 && H <= HMAX;
+    if (quart) {
+        const int zq = lane % Z, kq = lane / Z, hq = H / 4;
+        if (kq < 4) {
+            float wq[HMAX / 4];
+#pragma unroll
+            for (int i = 0; i < HMAX / 4; ++i)
+                if (i < hq) wq[i] = p.l2h_w[(size_t)(kq * hq + i) * Z + zq];
+#pragma unroll
+            for (int i = 0; i < HMAX / 4; ++i)
+                if (i < hq) dz_q = fmaf(dl[w][kq * hq + i], wq[i], dz_q);
+        }
+        const float d1 = __shfl(dz_q, lane + Z, 64), d2 = __shfl(dz_q, lane + 2 * Z, 64), d3 = __shfl(dz_q, lane + 3 * Z, 64);
+        dz_q = (dz_q + d1) + (d2 + d3);
+    }
     if (lane < Z) {
         float dz = 0.f;
-        for (int k = 0; k < H; ++k) dz = fmaf(dl[w][k], p.l2h_w[(size_t)k * Z + lane], dz);
+        if (quart) dz = dz_q;
+        else for (int k = 0; k < H; ++k) dz = fmaf(dl[w][k], p.l2h_w[(size_t)k * Z + lane], dz);
         const size_t i = (size_t)row * Z + lane;
         const float sd = expf(0.5f * hb.lv[i]);
         const float dm = dz + d_mu[i];
@@ -184,8 +230,17 @@ __global__ void __launch_bounds__(64 * HB_WAVES) head_bwd_kernel(int B, int H, i
         dxh[i] = 0.f; xh[i] = 0.f;
         if (k < H) {
             float dy = 0.f;
-            for (int z = 0; z < Z; ++z)
-                dy += dmz[w][z] * p.mu_w[(size_t)z * H + k] + dmz[w][ZMAX + z] * p.lv_w[(size_t)z * H + k];
+            for (int z0 = 0; z0 < Z; z0 += 8) {                      // 16 weight loads in flight per trip, same order of additions
+                float wm8[8], wl8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int z = z0 + u < Z ? z0 + u : 0;
+                    wm8[u] = p.mu_w[(size_t)z * H + k]; wl8[u] = p.lv_w[(size_t)z * H + k];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (z0 + u < Z) dy += dmz[w][z0 + u] * wm8[u] + dmz[w][ZMAX + z0 + u] * wl8[u];
+            }
             if (layer_norm) {
                 xh[i] = hb.xhat[(size_t)row * H + k];
                 dxh[i] = dy * p.ln_w[k];
@@ -446,23 +501,44 @@ __global__ void __launch_bounds__(256) vae_loss_kernel(int B, int T, int D, int 
         // L2 round trip per element and took 19 us); per-thread summation order is fixed, so the result is reproducible
         const int nz4 = ((reinterpret_cast<uintptr_t>(mu) | reinterpret_cast<uintptr_t>(lv) | reinterpret_cast<uintptr_t>(d_mu) |
                           reinterpret_cast<uintptr_t>(d_lv)) & 15) == 0 ? (nz & ~3) : 0;
-        for (int i = 4 * threadIdx.x; i < nz4; i += 4 * 256) {
-            const f32x4 m4 = *reinterpret_cast<const f32x4*>(mu + i), l4 = *reinterpret_cast<const f32x4*>(lv + i);
-            f32x4 gm, gl;
+        // eight passes' loads in flight at once (B * Z = 8192 is eight passes: issued one pass per trip, each waited out its own L2
+        // round trip, and this one-block kernel took 10.7 us); same per-thread order of additions
+        for (int i0 = 4 * threadIdx.x; i0 < nz4; i0 += 8 * 4 * 256) {
+            f32x4 m8[8], l8[8];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float e = expf(l4[k]);
-                ks += 1.0f + l4[k] - m4[k] * m4[k] - e;
-                gm[k] = kz * m4[k]; gl[k] = -0.5f * kz * (1.0f - e);
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 4 * 256, ic = i < nz4 ? i : 4 * (int)threadIdx.x;
+                m8[u] = *reinterpret_cast<const f32x4*>(mu + ic); l8[u] = *reinterpret_cast<const f32x4*>(lv + ic);
             }
-            if (d_mu) { *reinterpret_cast<f32x4*>(d_mu + i) = gm; *reinterpret_cast<f32x4*>(d_lv + i) = gl; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 4 * 256;
+                if (i < nz4) {
+                    f32x4 gm, gl;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float e = expf(l8[u][k]);
+                        ks += 1.0f + l8[u][k] - m8[u][k] * m8[u][k] - e;
+                        gm[k] = kz * m8[u][k]; gl[k] = -0.5f * kz * (1.0f - e);
+                    }
+                    if (d_mu) { *reinterpret_cast<f32x4*>(d_mu + i) = gm; *reinterpret_cast<f32x4*>(d_lv + i) = gl; }
+                }
+            }
         }
         for (int i = nz4 + threadIdx.x; i < nz; i += 256) {
             const float m = mu[i], l = lv[i], e = expf(l);
             ks += 1.0f + l - m * m - e;
             if (d_mu) { d_mu[i] = kz * m; d_lv[i] = -0.5f * kz * (1.0f - e); }
         }
-        for (int i = threadIdx.x; i < B; i += 256) rs += score[i];
+        {
+            float sv[4];                                  // B <= 1024 windows in one round of loads, more in a loop
+            for (int i0 = threadIdx.x; i0 < B; i0 += 4 * 256) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int i = i0 + u * 256; sv[u] = score[i < B ? i : 0]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (i0 + u * 256 < B) rs += sv[u];
+            }
+        }
         ks = wave_sum(ks); rs = wave_sum(rs);
         if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ks; red[1][threadIdx.x >> 6] = rs; }
         __syncthreads();
