@@ -156,7 +156,35 @@ __global__ void __launch_bounds__(64 * HB_WAVES) head_bwd_kernel(int B, int H, i
     if (rowwave)
         for (int m = lane; m < G; m += 64) ds[w][m] = dpre_tsum[(size_t)row * G + m];
     __syncthreads();
-    {
+    if (H == 128 && (reinterpret_cast<uintptr_t>(W_ih_dec0) & 15) == 0) {
+        // H = 128: a weight row is 32 lanes x 16 bytes, so a wave reads TWO rows per load instruction (lane half hp takes the odd / even
+        // row of a pair) and its 32 rows are 16 loads per lane, all in flight at once (the 4-byte form needed 64 loads in four
+        // dependent batches); the two halves are combined by one shuffle, wave slices as before.
+        const int hp = lane >> 5, k4 = (lane & 31) * 4, mq = G / HB_WAVES;       // mq = 32 rows per wave
+        f32x4 wrow[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) wrow[i] = *reinterpret_cast<const f32x4*>(W_ih_dec0 + (size_t)(wv * mq + 2 * i + hp) * H + k4);
+        f32x4 acc4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc4[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int m = wv * mq + 2 * i + hp;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = ds[r][m];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc4[r][e] = fmaf(d, wrow[i][e], acc4[r][e]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float o = __shfl_xor(acc4[r][e], 32, 64);               // even-row half + odd-row half
+                if (hp == 0) part[wv][r][k4 + e] = acc4[r][e] + o;
+            }
+    } else {
         float acc[4][HMAX / 64];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -265,8 +293,9 @@ __global__ void __launch_bounds__(64 * HB_WAVES) head_bwd_kernel(int B, int H, i
 // All eight head parameter gradients in ONE launch: every output element is a fixed-order sum over the B windows of
 // a product P[b][i] * Q[b][j] (weights) or of P[b][i] alone (biases, LayerNorm).  Block = 64 outputs x 4 window groups.
 struct HeadGradPtrs { float *l2h_w, *l2h_b, *mu_w, *mu_b, *lv_w, *lv_b, *ln_w, *ln_b; };
-__global__ void __launch_bounds__(256) head_grads_kernel(int B, int H, int Z, int layer_norm, HeadBufs hb, HeadGradPtrs g) {
-    __shared__ float red[4][64];
+constexpr int HG_GROUPS = 16;       // window groups per block: B / 16 products per thread (with 4 groups the 128-trip load chain was 11.7 us)
+__global__ void __launch_bounds__(64 * HG_GROUPS) head_grads_kernel(int B, int H, int Z, int layer_norm, HeadBufs hb, HeadGradPtrs g) {
+    __shared__ float red[HG_GROUPS][64];
     const int e = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
     const int HZ = H * Z;
     const int n_total = 3 * HZ + H + 2 * Z + (layer_norm ? 2 * H : 0);
@@ -288,15 +317,21 @@ __global__ void __launch_bounds__(256) head_grads_kernel(int B, int H, int Z, in
     if (P) {
         if (Q) {
 #pragma unroll 8
-            for (int b = grp; b < B; b += 4) s = fmaf(P[(size_t)b * ldp + i], Q[(size_t)b * ldq + j], s);
+            for (int b = grp; b < B; b += HG_GROUPS) s = fmaf(P[(size_t)b * ldp + i], Q[(size_t)b * ldq + j], s);
         } else {
 #pragma unroll 8
-            for (int b = grp; b < B; b += 4) s += P[(size_t)b * ldp + i];
+            for (int b = grp; b < B; b += HG_GROUPS) s += P[(size_t)b * ldp + i];
         }
     }
     red[grp][threadIdx.x & 63] = s;
     __syncthreads();
-    if (grp == 0 && out) *out = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (grp == 0 && out) {
+        float t = 0.f;
+#pragma unroll
+        for (int q4 = 0; q4 < HG_GROUPS; q4 += 4)
+            t += (red[q4][threadIdx.x] + red[q4 + 1][threadIdx.x]) + (red[q4 + 2][threadIdx.x] + red[q4 + 3][threadIdx.x]);
+        *out = t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ output layer + score
@@ -916,7 +951,7 @@ int launch_head_grads(int B, int H, int Z, int layer_norm, const HeadBufs& hb, f
                       float* lv_w, float* lv_b, float* ln_w, float* ln_b, hipStream_t s) {
     HeadGradPtrs g{l2h_w, l2h_b, mu_w, mu_b, lv_w, lv_b, ln_w, ln_b};
     const int n_total = 3 * H * Z + H + 2 * Z + (layer_norm ? 2 * H : 0);
-    SHM_LAUNCH(head_grads_kernel, dim3(ceil_div(n_total, 64)), dim3(256), 0, s, B, H, Z, layer_norm, hb, g);
+    SHM_LAUNCH(head_grads_kernel, dim3(ceil_div(n_total, 64)), dim3(64 * HG_GROUPS), 0, s, B, H, Z, layer_norm, hb, g);
     SHM_LAUNCH_CHECK();
     return SHM_OK;
 }
