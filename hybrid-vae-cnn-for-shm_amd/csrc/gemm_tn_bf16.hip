@@ -322,7 +322,6 @@ __global__ void __launch_bounds__(512) gemm_tn_bf16_v2_kernel(GemmTnArgsB a, int
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS-DMA may outlive the workgroup
 
-    if (a.drop_seed == 0xDEADull && acc[0][0][0] != 12345.678f) return;   // PROBE
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -396,7 +395,6 @@ int launch_gemm_tn_bf16(const GemmTnArgsB& a, hipStream_t s, ReduceJobs* defer) 
     SHM_REQUIRE(a.NB == 1 || (a.Bm2 && a.C2), SHM_EINVAL, "gemm_tn_bf16: second operand missing");
     SHM_REQUIRE(a.nseg <= 1 || (a.A_lo && a.Bm_lo && (a.NB == 1 || a.Bm2_lo) && (!a.Bx || a.Bx_lo) && !(a.drop_p > 0.f)), SHM_EINVAL,
                 "gemm_tn_bf16: split-precision operands need every lo plane (and no in-kernel dropout)");
-    if (getenv("SHM_PROBE_GEMM_NOSTORE")) const_cast<GemmTnArgsB&>(a).drop_seed = 0xDEADull;   // PROBE
     const bool v2 = v2_ok(a);
     SHM_REQUIRE(a.bcast_T == 0 || v2, SHM_EINVAL, "gemm_tn_bf16: the per-window operand needs the H = 128 kernel");
     const Geo g = v2 ? geometry_v2(a.R, a.M) : geometry(a.R, a.M, a.N, a.NB);
