@@ -118,8 +118,9 @@ def host_cores():
     return max(1, min(n, 16))
 
 
-def cpu_baseline(sample_windows=128, max_steps=3, budget_s=25.0):
-    """The reference CPU path (oracle/torch_cpu.py: ATen LSTM etc.) timed on this box's host cores, bounded sample."""
+def cpu_baseline(sample_windows=128, max_steps=24, budget_s=12.0):
+    """The reference CPU path (oracle/torch_cpu.py: ATen LSTM etc.) timed on this box's host cores, bounded sample: about 10 s of CPU
+    work (steps of 128 windows until the budget is spent, at most 24)."""
     import torch
     from oracle.torch_cpu import TorchCpuVAE
     from Scripts.Models.temporal_vae import TemporalVAE
@@ -156,7 +157,7 @@ def cnn_alg_flops(name, B):
             "cnn.bwd_fused2": 2 * conv2, "cnn.bwd_fused1": conv1}.get(name, 0)
 
 
-def cnn_cpu_baseline(budget_s=8.0, max_steps=40):
+def cnn_cpu_baseline(budget_s=6.0, max_steps=120):
     """The reference CNN step on this box's host cores (oracle/torch_cpu_cnn.py: ATen conv2d / batch_norm / max_pool2d / linear / Adam)."""
     import torch
     from oracle.torch_cpu_cnn import TorchCpuCNN
