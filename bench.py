@@ -414,7 +414,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200, help="timed steps (SURVEY.md section 8d protocol: 20 warm-up + 200 timed)")
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-steps", type=int, default=2)
+    ap.add_argument("--profile-steps", type=int, default=4, help="steps profiled per leg with per-launch HIP events, right after its timed region")
     ap.add_argument("--precision", choices=["bf16", "fp32", "split"], default="bf16",
                     help="headline leg.  bf16 (default): BASELINE.json configs[1]; split: bf16 hi+lo operand pairs, the 1e-4 parity-grade fast "
                          "path; fp32: exact-f32 MFMA")
