@@ -322,6 +322,8 @@ extern "C" int shm_vae_plan_create(const shm_vae_config* cfg, int32_t B, int32_t
             const size_t eb2 = gemm_tn_bf16_partial_elems((int)(qt * SHM_WPT * T), 4 * H, H, 2);  // decoder layer 0: dW_ih and dW_hh
             if (eb2 > eb) eb = eb2;
             p->gemm_partial_b = take(eb > 0 ? eb : 1);
+        }
+        if (bf) {        // the fp32 dec0 dW_ih GEMM's own split-K scratch (pair path and split path batch it with the layer's other reductions)
             const size_t ec = gemm_tn_partial_elems(B, 4 * H, H);
             p->gemm_partial_c = take(ec > 0 ? ec : 1);
         }
@@ -911,26 +913,31 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
                 KernelTimer kt(gnm, gs);
                 LoPlanes lo;
                 lo.A = dpl; lo.Bh = at<char>(ws, stp[l].h_lo); lo.Bin = nullptr; lo.Bx = nullptr;
+                // every split-K / per-window reduction of this layer in ONE launch behind its products (was three or four small launches)
+                ReduceJobs rj;
+                rj.n = 0;
+                float* part = at<float>(ws, p->gemm_partial);      // one layer at a time on gs: reduced below before the next product starts
                 if (l > 0) {
                     const bool dr = drop > 0.f;
                     const void* xin = dr ? at<char>(ws, stp[l].xdrop) : at<char>(ws, stp[l - 1].h_seq);
                     lo.Bin = dr ? at<char>(ws, stp[l].xdrop_lo) : at<char>(ws, stp[l - 1].h_lo);
-                    if ((r2 = gemm_bf(dph, G, xin, grads + stp[l].w_ih, 0.f, stack, at<char>(ws, stp[l].h_seq), grads + stp[l].w_hh, Rt, nullptr, nullptr,
+                    if ((r2 = gemm_bf(dph, G, xin, grads + stp[l].w_ih, 0.f, stack, at<char>(ws, stp[l].h_seq), grads + stp[l].w_hh, Rt, &rj, part,
                                       nullptr, nullptr, &lo))) return r2;
                 } else if (stp[l].in_const) {
-                    if ((r2 = gemm_bf(dph, G, nullptr, nullptr, 0.f, 0, at<char>(ws, stp[l].h_seq), grads + stp[l].w_hh, Rt, nullptr, nullptr,
+                    if ((r2 = gemm_bf(dph, G, nullptr, nullptr, 0.f, 0, at<char>(ws, stp[l].h_seq), grads + stp[l].w_hh, Rt, &rj, part,
                                       nullptr, nullptr, &lo))) return r2;
                     // dW_ih = (sum_t dpre_t)^T h0: B rows, exact fp32 (temporal_vae.py:68 repeats h0, so the T products collapse)
-                    if ((r2 = gemm(tsum, G, G, hb.h0, H, H, B, grads + stp[l].w_ih, 0, 0, 0.f, 0))) return r2;
+                    if ((r2 = gemm(tsum, G, G, hb.h0, H, H, B, grads + stp[l].w_ih, 0, 0, 0.f, 0, 0, 0, &rj, at<float>(ws, p->gemm_partial_c)))) return r2;
                 } else {
                     const bool xfuse = H == 128;      // dW_ih = dpre^T x as a 16-column third product of the same launch
                     lo.Bx = at<char>(ws, p->x_tb_lo);
-                    if ((r2 = gemm_bf(dph, G, nullptr, nullptr, 0.f, 0, at<char>(ws, stp[l].h_seq), grads + stp[l].w_hh, Rt, nullptr, nullptr,
+                    if ((r2 = gemm_bf(dph, G, nullptr, nullptr, 0.f, 0, at<char>(ws, stp[l].h_seq), grads + stp[l].w_hh, Rt, &rj, part,
                                       xfuse ? at<char>(ws, p->x_tb) : nullptr, xfuse ? grads + stp[l].w_ih : nullptr, &lo))) return r2;
                     if (!xfuse && (r2 = launch_narrow_tn(dph, 1, G, G, x0, D, Rt, grads + stp[l].w_ih, 1, nullptr, at<float>(ws, p->narrow_scratch), gs, T, B,
-                                                         nullptr, dpl))) return r2;
+                                                         &rj, dpl))) return r2;
                 }
-                return launch_reduce_partials(tsum, B, (size_t)G, grads + stp[l].b_ih, grads + stp[l].b_hh, gs);
+                if ((r2 = reduce_jobs_add(rj, tsum, B, (size_t)G, (size_t)G, grads + stp[l].b_ih, grads + stp[l].b_hh))) return r2;
+                return launch_reduce_batch(rj, gs);
             });
         };
         if (sp && NCb > 1) {
