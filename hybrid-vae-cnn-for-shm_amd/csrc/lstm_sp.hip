@@ -114,6 +114,8 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_sp_kernel(LstmFwdArgsS a) {
     const int xb0 = tile * WPT + xj0 < B ? tile * WPT + xj0 : B - 1;
     const f32x4* xp = reinterpret_cast<const f32x4*>(a.xproj) + ((size_t)tile * (MODE == 1 ? 1 : T) * NW + ht) * 64 + lane;
     struct Slot { f32x4 v; };
+    // input slots = prefetch distance in steps: 6 for the projection stream (16 bytes per lane and step out of HBM, ~5 us ahead), 3 for raw x
+    constexpr int NS = MODE == 0 ? 6 : 3;
     auto fetch = [&](Slot& X, int t) {           // mode 0: projection of step t; mode 2: x of step t; clamped, never predicated
         const int tc = t < t1 ? t : t1 - 1;        // never reads another chunk's rows (they may be being written right now)
         if constexpr (MODE == 0) X.v = xp[(size_t)tc * NW * 64];
@@ -190,11 +192,11 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_sp_kernel(LstmFwdArgsS a) {
             if (t + 1 < t1) x_commit(X.v[0], t + 1, cur ^ 1);
 #pragma unroll
             for (int g = 0; g < 4; ++g) gate[g] = redeal_hl(acc[g]) + bias_c[g];
-            fetch(X, t + 4);
+            fetch(X, t + 1 + NS);
         } else if constexpr (MODE == 0) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) gate[g] = redeal_hl(acc[g]) + X.v[g];
-            fetch(X, t + 3);
+            fetch(X, t + NS);
         } else {
 #pragma unroll
             for (int g = 0; g < 4; ++g) gate[g] = redeal_hl(acc[g]) + xconst[g];
@@ -219,16 +221,16 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_sp_kernel(LstmFwdArgsS a) {
         __syncthreads();
     };
 
-    Slot X0, X1, X2;
+    Slot X[NS];
     constexpr int LEAD = MODE == 2 ? 1 : 0;       // mode 2 slots run one step ahead (x_{t+1} is staged during step t)
     int t = t0;
-    for (int k = (t1 - t0) % 3; k > 0; --k, ++t) { fetch(X0, t + LEAD); step(X0, t); }     // peel: the main loop runs whole triples
-    fetch(X0, t + LEAD); fetch(X1, t + 1 + LEAD); fetch(X2, t + 2 + LEAD);
+    for (int k = (t1 - t0) % NS; k > 0; --k, ++t) { fetch(X[0], t + LEAD); step(X[0], t); }     // peel: the main loop runs whole groups of NS
+#pragma unroll
+    for (int u = 0; u < NS; ++u) fetch(X[u], t + u + LEAD);
     __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0) once: only steady-state loads cross the back-edge
-    for (; t + 2 < t1; t += 3) {
-        step(X0, t);
-        step(X1, t + 1);
-        step(X2, t + 2);
+    for (; t + NS - 1 < t1; t += NS) {
+#pragma unroll
+        for (int u = 0; u < NS; ++u) step(X[u], t + u);
     }
     if constexpr (SAVE) { sv4[(size_t)(t1 - 1) * NW * 64] = r4_prev; sv2[(size_t)(t1 - 1) * NW * 64] = r2_prev; }
     h_flush(t1 - 1, t1 & 1);
@@ -278,6 +280,7 @@ __global__ void __launch_bounds__(4 * H) lstm_bwd_sp_kernel(LstmBwdArgsS a) {
     const f32x2* sv2 = reinterpret_cast<const f32x2*>(a.rec2) + ((size_t)tile * T * NW + ht) * 64 + lane;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
+    constexpr int NSB = DH == 2 ? 4 : (DH == 1 ? 5 : 6);                         // record slots = prefetch distance in steps (24 bytes per lane and step out of HBM)
     auto fetch = [&](PrefS& P, int t) {
         const int tc = t < t0 ? t0 : t;            // never reads another chunk's rows
         P.r4 = sv4[(size_t)tc * NW * 64];
@@ -335,7 +338,7 @@ __global__ void __launch_bounds__(4 * H) lstm_bwd_sp_kernel(LstmBwdArgsS a) {
             dpl[(g * 16 + 4 + cj) * RS + cu] = s[1];
             tsum[g] += dpre[g];
         }
-        fetch(P, t - 4);
+        fetch(P, t - NSB);
         __syncthreads();
         *reinterpret_cast<bf16x8*>(f_dst + (size_t)t * WPT * 4 * H) = *reinterpret_cast<const bf16x8*>(dpl + f_img_off);
         const bf16_t* brow = dpl + (q * 16 + j) * RS;
@@ -353,19 +356,18 @@ __global__ void __launch_bounds__(4 * H) lstm_bwd_sp_kernel(LstmBwdArgsS a) {
     };
 
     __syncthreads();
-    PrefS P0, P1, P2, P3;
+    PrefS P[NSB];
     f32x2* const bst = a.state ? reinterpret_cast<f32x2*>(a.state) + ((size_t)tile * NW + ht) * 64 + lane : nullptr;
     if (t1 < T) { const f32x2 st = bst[0]; dc = st[0]; dh_rec = st[1]; }      // continue the chunk above: (dc, dh_rec) of step t1
     else if (a.dh_last) dh_rec = vmask * a.dh_last[(size_t)bc * H + cu];
     int t = t1 - 1;
-    for (int k = (t1 - t0) & 3; k > 0; --k, --t) { fetch(P0, t); step(P0, t); }
-    fetch(P0, t); fetch(P1, t - 1); fetch(P2, t - 2); fetch(P3, t - 3);
+    for (int k = (t1 - t0) % NSB; k > 0; --k, --t) { fetch(P[0], t); step(P[0], t); }
+#pragma unroll
+    for (int u = 0; u < NSB; ++u) fetch(P[u], t - u);
     __builtin_amdgcn_s_waitcnt(0x0F70);
-    for (; t >= t0 + 3; t -= 4) {
-        step(P0, t);
-        step(P1, t - 1);
-        step(P2, t - 2);
-        step(P3, t - 3);
+    for (; t >= t0 + NSB - 1; t -= NSB) {
+#pragma unroll
+        for (int u = 0; u < NSB; ++u) step(P[u], t - u);
     }
     if (t0 > 0 && bst) bst[0] = f32x2{dc, dh_rec};
     if (cvalid && a.dpre_tsum) {                   // sum_t dpre: the chunk that runs first (t1 == T) writes, later chunks add
