@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_sp_kernel(LstmFwdArgsS a) {
     const f32x4* xp = reinterpret_cast<const f32x4*>(a.xproj) + ((size_t)tile * (MODE == 1 ? 1 : T) * NW + ht) * 64 + lane;
     struct Slot { f32x4 v; };
     // input slots = prefetch distance in steps: 6 for the projection stream (16 bytes per lane and step out of HBM, ~5 us ahead), 3 for raw x
-    constexpr int NS = MODE == 0 ? 6 : 3;
+    constexpr int NS = MODE == 0 ? 8 : 3;
     auto fetch = [&](Slot& X, int t) {           // mode 0: projection of step t; mode 2: x of step t; clamped, never predicated
         const int tc = t < t1 ? t : t1 - 1;        // never reads another chunk's rows (they may be being written right now)
         if constexpr (MODE == 0) X.v = xp[(size_t)tc * NW * 64];
