@@ -340,7 +340,7 @@ __device__ __forceinline__ void lstm_bwd_fused_dx_body(const LstmBwdArgsB& a, co
             dpl[(g * 16 + cj) * RS + cu] = (bf16_t)dpre[g];
             tsum[g] += dpre[g];
         }
-        fetch(R, t - 4);
+        fetch(R, t - 8);                                   // refill the slot: 8 steps (~7 us) of latency cover
         if constexpr (SUB == 3) { chunk_commit(); chunk_load(c - 2); }
         __syncthreads();
         {
@@ -372,12 +372,25 @@ __device__ __forceinline__ void lstm_bwd_fused_dx_body(const LstmBwdArgsB& a, co
     if (T & 3) { c1 = ctop - 1; if (c1 >= 0) sync_chunk(c1); }      // the peeled steps use the partial top chunk
     chunk_load(c1 - 1);
 
-    u32x3 R0, R1, R2, R3;
+    // eight record slots = eight steps of look-ahead (two hand-off chunks); an odd chunk at the end runs on the first four slots, which
+    // by then hold exactly its steps
+    u32x3 R0, R1, R2, R3, R4, R5, R6, R7;
     int t = T - 1;
     for (int k = T & 3; k > 0; --k, --t) { fetch(R0, t); step(R0, t, IntC<-1>{}); }
     fetch(R0, t); fetch(R1, t - 1); fetch(R2, t - 2); fetch(R3, t - 3);
+    fetch(R4, t - 4); fetch(R5, t - 5); fetch(R6, t - 6); fetch(R7, t - 7);
     __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0) once (see lstm_bwd_body)
-    for (; t >= 3; t -= 4) {
+    for (; t >= 7; t -= 8) {
+        step(R0, t, IntC<3>{});
+        step(R1, t - 1, IntC<2>{});
+        step(R2, t - 2, IntC<1>{});
+        step(R3, t - 3, IntC<0>{});
+        step(R4, t - 4, IntC<3>{});
+        step(R5, t - 5, IntC<2>{});
+        step(R6, t - 6, IntC<1>{});
+        step(R7, t - 7, IntC<0>{});
+    }
+    if (t >= 3) {
         step(R0, t, IntC<3>{});
         step(R1, t - 1, IntC<2>{});
         step(R2, t - 2, IntC<1>{});
