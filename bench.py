@@ -43,7 +43,8 @@ def kernel_alg_flops(name, B, path="fp32"):
     kind, _, inst = name.partition(".")
     if kind == "lstm_fwd":
         if inst in ("enc", "dec"):                                          # layer-pipelined launch: both layers of the stack
-            return kernel_alg_flops(f"lstm_fwd.{inst}0", B, path) + kernel_alg_flops(f"lstm_fwd.{inst}1", B, path)
+            fused = kernel_alg_flops(f"xproj.{inst}1", B, path) if path == "split" else 0     # split pair launch: layer 1's projection is inside
+            return kernel_alg_flops(f"lstm_fwd.{inst}0", B, path) + kernel_alg_flops(f"lstm_fwd.{inst}1", B, path) + fused
         k_in = {"enc0": D, "enc1": H, "dec0": 0, "dec1": H}[inst]          # dec0: constant input, projected once
         if path == "split":
             return B * T * 2 * G * ((D if inst == "enc0" else 0) + H)
@@ -80,7 +81,8 @@ PMC_KERNELS = {
                     "conv2_dx": "conv3x3_fwd_mfma_kernel<32, 16, false, true>", "conv2_dw": "conv3x3_bwd_weight_ksplit_kernel<16, 32>",
                     "conv1_dw": "conv3x3_bwd_weight_mfma_kernel<2, 16, true>", "fc1_dw": "dense_dw_mfma_kernel<8>",
                     "fc1_fwd": "linear_fwd_mfma_kernel", "fc1_dx": "linear_bwd_dx_mfma_kernel"}},
-    "split": {"lstm_fwd": {"enc0": "lstm_fwd_sp_kernel<128, 2, true>", "enc1": "lstm_fwd_sp_kernel<128, 0, true>",
+    "split": {"lstm_fwd": {"enc": "lstm_fwd_pair_sp_kernel<128, 2", "dec": "lstm_fwd_pair_sp_kernel<128, 1",
+                           "enc0": "lstm_fwd_sp_kernel<128, 2, true>", "enc1": "lstm_fwd_sp_kernel<128, 0, true>",
                            "dec0": "lstm_fwd_sp_kernel<128, 1, true>", "dec1": "lstm_fwd_sp_kernel<128, 0, true>"},
               "lstm_bwd": {"enc0": "lstm_bwd_sp_kernel<128, 1>", "dec0": "lstm_bwd_sp_kernel<128, 1>",
                            "enc1": "lstm_bwd_sp_kernel<128, 0>", "dec1": "lstm_bwd_sp_kernel<128, 2>"}},

@@ -279,7 +279,7 @@ extern "C" int shm_vae_plan_create(const shm_vae_config* cfg, int32_t B, int32_t
             }
         }
     }
-    if (bf && !sp && L == 2) p->pair_sync = take_bytes(2 * lstm_fwd_pair_sync_bytes(B));      // two blocks, used alternately
+    if (bf && L == 2) p->pair_sync = take_bytes(2 * lstm_fwd_pair_sync_bytes(B));      // two blocks, used alternately (bf16 and split pair launches)
     if (bf) p->misc = take_bytes(misc_bytes(B));                     // sticky error word | 256 B of zeros | out_fwd's per-tile arrival counters
     if (bf) p->score_part = take((size_t)4 * ceil_div(B, SHM_WPT) * SHM_WPT);
     if (bf) p->x_tb = take_bytes(2 * Rq * 16);
@@ -376,6 +376,9 @@ static int sp_chunks(const shm_vae_plan* p, bool records) {
     const char* e = getenv("SHM_SP_CHUNKS");             // read per call: a test flips it inside one process
     // default: off for the training passes (measured above), 4 for a forward that saves no BPTT records (inference plans: scoring,
     // encode / decode) — without the 402 MB record stream per layer two recurrences do fit side by side: 502 -> 561 k windows/s scored
+    // round 3: the forward of a 2-layer stack is ONE layer-pipelined launch (lstm_fwd_pair_sp_kernel) unless pair launches are switched
+    // off; the launch-level chunk pipeline remains for that case and for an explicit SHM_SP_CHUNKS
+    if (!e && pair_launch_enabled()) return 1;
     int want = e ? atoi(e) : (records ? SHM_SP_CHUNKS_DEFAULT : 4);
     if (want < 1) want = 1;
     if (want > 8) want = 8;
@@ -421,10 +424,13 @@ extern "C" int shm_vae_pack_weights(shm_vae_plan* p, const float* params, void* 
             for (int st = 0; st < 2; ++st) {
                 const LayerInst& li = st == 0 ? p->enc[l] : p->dec[l];
                 add(params + li.b_ih, params + li.b_hh, at<float>(ws, li.bsum), 2, 0);
-                add(params + li.w_ih, nullptr, at<bf16_t>(ws, li.Wx), 0, li.In);
+                // split path, layers whose input is a hidden vector (layers >= 1 and the constant-input decoder layer 0): W_ih as fp16 +
+                // fp8 residual (kinds 7 / 8, lstm_sp.hip: x_convert); everything else as bf16 (pairs)
+                const bool w16 = sp && (l > 0 || li.in_const);
+                add(params + li.w_ih, nullptr, at<bf16_t>(ws, li.Wx), w16 ? 7 : 0, li.In);
                 add(params + li.w_hh, nullptr, at<bf16_t>(ws, li.Wh), 0, H);
                 if (sp) {
-                    add(params + li.w_ih, nullptr, at<bf16_t>(ws, li.Wx_lo), 5, li.In);
+                    add(params + li.w_ih, nullptr, at<bf16_t>(ws, li.Wx_lo), w16 ? 8 : 5, li.In);
                     add(params + li.w_hh, nullptr, at<bf16_t>(ws, li.Wh_lo), 5, H);
                 }
                 if (p->training) {
@@ -537,8 +543,52 @@ static int vae_forward_impl(shm_vae_plan* p, const float* x, const float* eps, c
     const bool sp = c.precision == SHM_PREC_SPLIT;
     const int NC = sp ? sp_chunks(p, save) : 1;
     if (NC > 1 && (rc = ensure_side_stream(p))) return rc;
+    const bool sp_pair = sp && L == 2 && NC == 1 && pair_launch_enabled() && !getenv("SHM_SP_CHUNKS");
     auto run_stack_sp = [&](LayerInst* st, const float* in0, uint32_t stack, float* h_last) -> int {
         const int qt = ceil_div(B, SHM_WPT);
+        if (sp_pair) {
+            // both layers in ONE launch: layer 0 hands its h planes to layer 1 inside the launch, layer 1 forms its own input projection
+            // (no xproj launch, no 268 MB projection stream); bit-identical to the one-launch-per-layer form below
+            const char* sn = stack == 0 ? "enc" : "dec";
+            char nm[32];
+            LstmFwdPairArgsS pa;
+            memset(&pa, 0, sizeof(pa));
+            for (int l = 0; l < 2; ++l) {
+                LstmFwdArgsS& a = l ? pa.l1 : pa.l0;
+                a.Wh_hi = at<bf16_t>(ws, st[l].Wh); a.Wh_lo = at<bf16_t>(ws, st[l].Wh_lo);
+                a.h_hi = at<bf16_t>(ws, st[l].h_seq); a.h_lo = at<bf16_t>(ws, st[l].h_lo);
+                a.rec4 = save ? at<float>(ws, st[l].saved) : nullptr; a.rec2 = save ? at<float>(ws, st[l].saved_c) : nullptr;
+                a.B = B; a.T = T; a.In = st[l].In;
+            }
+            if (!st[0].in_const) {
+                pa.l0.mode = 2; pa.l0.x = in0; pa.l0.Wx_hi = at<bf16_t>(ws, st[0].Wx); pa.l0.Wx_lo = at<bf16_t>(ws, st[0].Wx_lo); pa.l0.bias = at<float>(ws, st[0].bsum);
+                if (save) { pa.l0.x_hi = at<bf16_t>(ws, p->x_tb); pa.l0.x_lo = at<bf16_t>(ws, p->x_tb_lo); }
+            } else {        // decoder layer 0: one projection per window (temporal_vae.py:68 repeats h0 over T), its own small launch
+                XprojArgsS xa;
+                memset(&xa, 0, sizeof(xa));
+                xa.W_hi = at<bf16_t>(ws, st[0].Wx); xa.W_lo = at<bf16_t>(ws, st[0].Wx_lo); xa.bias = at<float>(ws, st[0].bsum);
+                xa.out = at<float>(ws, st[0].xproj);
+                int r = launch_split_planes(in0, (size_t)B * H, (size_t)qt * SHM_WPT * H, at<bf16_t>(ws, p->h0_bf), at<bf16_t>(ws, p->h0_lo), s);
+                if (r) return r;
+                xa.in_hi = at<bf16_t>(ws, p->h0_bf); xa.in_lo = at<bf16_t>(ws, p->h0_lo); xa.rows = qt * SHM_WPT;
+                snprintf(nm, sizeof(nm), "xproj.%s0", sn);
+                KernelTimer kt(nm, s);
+                if ((r = launch_xproj_sp(H, xa, s))) return r;
+                pa.l0.mode = 1; pa.l0.xproj = at<float>(ws, st[0].xproj);
+            }
+            pa.l1.mode = 3; pa.l1.h_last = h_last;
+            pa.l1.Wx_hi = at<bf16_t>(ws, st[1].Wx); pa.l1.Wx_lo = at<bf16_t>(ws, st[1].Wx_lo); pa.l1.bias = at<float>(ws, st[1].bsum);
+            pa.l1.in_hi = at<bf16_t>(ws, st[0].h_seq); pa.l1.in_lo = at<bf16_t>(ws, st[0].h_lo);
+            pa.l1.drop_p = drop; pa.l1.drop_seed = drop_seed; pa.l1.drop_stack = stack;
+            if (drop > 0.f) { pa.l1.xd_hi = at<bf16_t>(ws, st[1].xdrop); pa.l1.xd_lo = at<bf16_t>(ws, st[1].xdrop_lo); }
+            pa.sync = at<unsigned>(ws, p->pair_sync + (size_t)p->sync_next * lstm_fwd_pair_sync_bytes(B));
+            pa.sync_other = at<unsigned>(ws, p->pair_sync + (size_t)(p->sync_next ^ 1) * lstm_fwd_pair_sync_bytes(B));
+            p->sync_next ^= 1;
+            pa.err = at<unsigned>(ws, p->misc);
+            snprintf(nm, sizeof(nm), "lstm_fwd.%s", sn);
+            KernelTimer kt(nm, s);
+            return launch_lstm_fwd_pair_sp(H, pa, s);
+        }
         if (NC > 1) {
             // launch-level layer pipeline over NC time chunks (see sp_chunks): s carries layer 0, the side stream projection + layer 1
             const char* sn = stack == 0 ? "enc" : "dec";

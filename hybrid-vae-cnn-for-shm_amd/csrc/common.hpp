@@ -64,6 +64,24 @@ __device__ __forceinline__ f32x4 mfma_bf16_16x16x32(bf16x8 a, bf16x8 b, f32x4 c)
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+// D[16x16] += A[16x32] * B[32x16], fp16 in / f32 accumulate (v_mfma_f32_16x16x32_f16); operand layout as the bf16 form.
+typedef _Float16 f16_t;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma_f16_16x16x32(f16x8 a, f16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+// D[16x16] += A[16x32] * B[32x16], fp8 (e4m3) in / f32 accumulate (v_mfma_f32_16x16x32_fp8_fp8): lane l supplies 8 consecutive k
+// (one byte each, k = 8*(l>>4)+e in byte e of the 64-bit operand) of row / column l&15, as the bf16 form does with 16-bit elements.
+__device__ __forceinline__ f32x4 mfma_fp8_16x16x32(long a, long b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a, b, c, 0, 0, 0);
+}
+// Split-precision input projections (lstm_sp.hip): W_ih ~ fp16(W) + e4m3((W - fp16(W)) * 2^15) * 2^-15 (15 significant bits in 3 bytes
+// per element, against 4 for the bf16 pair).  SHM_F8_MAX clamps what goes through v_cvt_pk_fp8_f32 (well inside e4m3's 448).
+#define SHM_W8_SCALE 32768.0f
+#define SHM_W8_UNSCALE (1.0f / 32768.0f)
+#define SHM_F8_MAX 224.0f
+
 // f32 -> bf16 by plain casts: hipcc emits v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN stays NaN)
 __device__ __forceinline__ bf16x4 cvt_bf16x4(f32x4 v) { return __builtin_convertvector(v, bf16x4); }
 __device__ __forceinline__ f32x4 cvt_f32x4(bf16x4 v) { return __builtin_convertvector(v, f32x4); }

@@ -221,8 +221,18 @@ struct LstmFwdArgsS {
     // written by the chunk before it) and from the h planes of step t0 - 1; a chunk with t1 < T leaves c_state for the next one.
     int t0, t1;
     float* c_state;
+    // fused layer 1 of a pair launch (lstm_fwd_sp_fused): the input is the hidden sequence of the layer below (its h planes), projected
+    // inside the recurrent workgroup with Wx_hi (kept in LDS) / Wx_lo (streamed from L2) and bias; dropout on that input as in XprojArgsS
+    const bf16_t* in_hi; const bf16_t* in_lo;
+    bf16_t* xd_hi; bf16_t* xd_lo;
+    float drop_p; uint64_t drop_seed; uint32_t drop_stack;
 };
 int launch_lstm_fwd_sp(int H, const LstmFwdArgsS& a, hipStream_t s);
+// both layers of a 2-layer stack in one launch: l0 in mode 1 / 2 hands its h planes to l1 inside the launch; l1 forms its own input
+// projection (no xproj launch, no projection stream).  sync / sync_other / err as in LstmFwdPairArgsB.  Bit-identical to the
+// one-launch-per-layer form.
+struct LstmFwdPairArgsS { LstmFwdArgsS l0, l1; unsigned* sync; unsigned* sync_other; unsigned* err; int role_lds_off; };
+int launch_lstm_fwd_pair_sp(int H, const LstmFwdPairArgsS& p, hipStream_t s);
 
 struct LstmBwdArgsS {
     const float* rec4; const float* rec2;

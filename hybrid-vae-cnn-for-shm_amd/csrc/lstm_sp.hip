@@ -23,6 +23,7 @@
 //     on the dependency chain, step 2.94 vs 2.93 ms) while the worst gradient tensor moved from 7e-6 to 2.7e-5 of its max;
 //   * backward: dpre_t leaves as hi / lo planes, dh_rec = W_hh^T dpre_t with the same column trick; dx = dpre W_ih of the
 //     layer below is the time-parallel dx_sp_kernel, weight gradients are gemm_tn_bf16.hip run over three plane pairs.
+#include <type_traits>
 #include "kernels.hpp"
 
 namespace shm {
@@ -53,9 +54,54 @@ __device__ __forceinline__ float redeal_hl(const f32x4 a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Operands of the input projection W_ih x + b of a layer whose input is a hidden sequence (round 3).  The input arrives as a bf16
+// pair (the h planes of the layer below); the projection uses
+//     W_ih ~ fp16(W) + e4m3((W - fp16(W)) 2^15) 2^-15          (pack kinds 7 / 8: 3 bytes per weight instead of 4)
+//     x    = f16 hi + f16 lo (exact: the pair carries <= 17 significant bits)  and  x8 = e4m3(x) for the residual product
+//     W x ~ [sum_k W8 x8] 2^-15 + sum_k (W16 xhi + W16 xlo)     in THIS order (k-step major, gates inner), bias added last
+// — the canonical MFMA sequence of both xproj_sp_kernel and lstm_fwd_sp_fused, so the two are bit-identical.  Emulated on the
+// north-star golden (tools/emulate_f16f8_projection.py): mu / logvar within 5e-6 of the fp32 reference, the bf16-pair form's level;
+// what it buys is a W_ih that is RESIDENT in the fused kernel (fp16 part 128 KB in LDS, fp8 part 32 VGPRs).
+struct XConv { f16x4 hi, lo; unsigned x8; bf16x4 dh, dl; };
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+template <bool DROP>
+__device__ __forceinline__ XConv x_convert(const u32x2 raw_hi, const u32x2 raw_lo, uint64_t seed, uint32_t stack, uint32_t idx, uint32_t thr, float dscale) {
+    const bf16x4 sh = __builtin_bit_cast(bf16x4, raw_hi), sl = __builtin_bit_cast(bf16x4, raw_lo);
+    XConv o;
+    float m[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float f = (float)sh[e] + (float)sl[e];
+        m[e] = DROP ? (drop_hash(seed, stack, idx + e) >= thr ? f * dscale : 0.f) : f;   // element index = tile-blocked row * H + unit (host replica: shm_dropout_keep_mask_tiled)
+        const f16_t h = (f16_t)m[e];
+        o.hi[e] = h; o.lo[e] = (f16_t)(m[e] - (float)h);
+        if (DROP) { const bf16x2 s2 = split2(m[e]); o.dh[e] = s2[0]; o.dl[e] = s2[1]; }
+        m[e] = fminf(fmaxf(m[e], -SHM_F8_MAX), SHM_F8_MAX);
+    }
+    int p8 = 0;
+    p8 = __builtin_amdgcn_cvt_pk_fp8_f32(m[0], m[1], p8, false);
+    p8 = __builtin_amdgcn_cvt_pk_fp8_f32(m[2], m[3], p8, true);
+    o.x8 = (unsigned)p8;
+    return o;
+}
+
+typedef __attribute__((address_space(1))) unsigned gu32;
+#define SHM_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+constexpr int DLY = 4;           // pair launch: a step's h planes are published DLY steps after they were stored
+constexpr int PAIR_GROUP = 128;  // pair launch: tiles per ticket group (two workgroups per tile -> 256 CUs)
+constexpr unsigned SPIN_MAX = 1u << 21;   // bounded consumer spin (a safety net: ~1 s); on expiry the err word is set
+
+// ---------------------------------------------------------------------------------------------------------------------
 // forward recurrence.  MODE 0: xproj stream, 1: xproj per window, 2: fp32 x (In <= 16) projected in the loop.
-template <int H, int MODE, bool SAVE>
-__global__ void __launch_bounds__(4 * H) lstm_fwd_sp_kernel(LstmFwdArgsS a) {
+// PRODUCE (pair launch, lstm_fwd_pair_sp_kernel): the h planes are consumed by the layer-1 workgroup of the same tile inside this
+// launch.  The hand-off is the sc1 form of lstm_fwd_bf16.hip (cdna_hip_programming.md section 6 Guideline 16, R1): wave 0 stores
+// BOTH planes of a step write-through (buffer_store ... sc1), retires the stores of DLY steps ago with a counted s_waitcnt and
+// publishes "steps < n are in memory" with one sc1 flag store.
+template <int H, int MODE, bool SAVE, bool PRODUCE>
+__device__ __forceinline__ void lstm_fwd_sp_body(const LstmFwdArgsS& a, const int tile, gu32* flag_out) {
     constexpr int NW = H / 16, NTHR = 64 * NW;
     constexpr int KSH = H / 32, KQH = H / 4, RSH = lds_row_stride(KQH);
     constexpr int KQX = 8, RSX = lds_row_stride(KQX);              // input operand of mode 2: one k-step of 32
@@ -64,7 +110,7 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_sp_kernel(LstmFwdArgsS a) {
     bf16_t* h_lds = smem_b;                     // [2][HBUF]   rows 0..3 hi, 4..7 lo, 8..15 zero
     bf16_t* x_lds = smem_b + 2 * HBUF;          // [2][XBUF]   (mode 2)
 
-    const int In = a.In > 0 ? a.In : 1, T = a.T, B = a.B, tile = blockIdx.x;
+    const int In = a.In > 0 ? a.In : 1, T = a.T, B = a.B;
     const int t0 = a.t0, t1 = a.t1;                                 // this launch walks steps [t0, t1) (a time chunk, or the whole window)
     const int tid = threadIdx.x, lane = tid & 63, ht = tid >> 6, q = lane >> 4, j = lane & 15;
     const int cj = j & 3, cr = j >> 2, cu = ht * 16 + q * 4 + cr;  // my cell: window cj of the tile, unit cu
@@ -104,9 +150,30 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_sp_kernel(LstmFwdArgsS a) {
     const int fjj = fc / (H / 8), fc8 = (fc - fjj * (H / 8)) * 8;
     const int f_img_off = ((fc8 / KQH) * 16 + fjj + 4 * fpl) * RSH + (fc8 % KQH);
     bf16_t* const f_dst = (fpl ? a.h_lo : a.h_hi) + (size_t)tile * T * WPT * H + (size_t)fc * 8;
+    // PRODUCE: thread c < NCH (all in wave 0) moves chunk c of BOTH planes; OPS = vector-memory instructions wave 0 issues per step (a lower bound)
+    constexpr int OPS = 2 + (SAVE ? 2 : 0) + (MODE == 2 ? 1 : 0);
+    const uint32_t seq_bytes = (uint32_t)T * WPT * H * 2;
+    const __amdgpu_buffer_rsrc_t hi_rsrc = make_rsrc(PRODUCE ? a.h_hi + (size_t)tile * T * WPT * H : nullptr, PRODUCE ? seq_bytes : 0);
+    const __amdgpu_buffer_rsrc_t lo_rsrc = make_rsrc(PRODUCE ? a.h_lo + (size_t)tile * T * WPT * H : nullptr, PRODUCE ? seq_bytes : 0);
+    const int pc = tid < NCH ? tid : 0, pjj = pc / (H / 8), pc8 = (pc - pjj * (H / 8)) * 8;
+    const int p_img_off = ((pc8 / KQH) * 16 + pjj) * RSH + (pc8 % KQH);
     auto h_flush = [&](int t_done, int buf) {
-        if (tid < 2 * NCH)
-            *reinterpret_cast<bf16x8*>(f_dst + (size_t)t_done * WPT * H) = *reinterpret_cast<const bf16x8*>(h_lds + buf * HBUF + f_img_off);
+        if constexpr (PRODUCE) {
+            if (tid < NCH) {
+                const u32x4 vh = *reinterpret_cast<const u32x4*>(h_lds + buf * HBUF + p_img_off);
+                const u32x4 vl = *reinterpret_cast<const u32x4*>(h_lds + buf * HBUF + p_img_off + 4 * RSH);
+                const uint32_t off = (uint32_t)(t_done * WPT * H + pc * 8) * 2;
+                __builtin_amdgcn_raw_buffer_store_b128(vh, hi_rsrc, off, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(vl, lo_rsrc, off, 0, 16);
+                // in-order vmcnt: with at most (DLY-1)*OPS younger operations outstanding the stores of step t_done - DLY + 1 have retired;
+                // publish one step more conservatively than that
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DLY - 1) * OPS) : "memory");
+                if (tid == 0 && t_done >= DLY) __hip_atomic_store(flag_out, (unsigned)(t_done - DLY + 1), SHM_RLX_AGENT);
+            }
+        } else {
+            if (tid < 2 * NCH)
+                *reinterpret_cast<bf16x8*>(f_dst + (size_t)t_done * WPT * H) = *reinterpret_cast<const bf16x8*>(h_lds + buf * HBUF + f_img_off);
+        }
     };
 
     // per-step input of this lane: mode 0 the f32x4 projection of its cell; mode 2 one element of x_{t+1} (thread e < WPT*In)
@@ -234,8 +301,332 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_sp_kernel(LstmFwdArgsS a) {
     }
     if constexpr (SAVE) { sv4[(size_t)(t1 - 1) * NW * 64] = r4_prev; sv2[(size_t)(t1 - 1) * NW * 64] = r2_prev; }
     h_flush(t1 - 1, t1 & 1);
+    if constexpr (PRODUCE) {
+        if (tid < NCH) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (tid == 0) __hip_atomic_store(flag_out, (unsigned)T, SHM_RLX_AGENT);
+        }
+    }
     if (t1 < T) { if (cst) cst[0] = c; }
     else if (a.h_last && cvalid) a.h_last[(size_t)cb * H + cu] = h;
+}
+
+template <int H, int MODE, bool SAVE>
+__global__ void __launch_bounds__(4 * H) lstm_fwd_sp_kernel(LstmFwdArgsS a) {
+    lstm_fwd_sp_body<H, MODE, SAVE, false>(a, blockIdx.x, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused layer-1 forward (round 3): the consumer half of lstm_fwd_pair_sp_kernel.  The input projection W_ih x_t + b of a layer whose
+// input is the hidden sequence of the layer below used to be its own time-parallel launch (xproj_sp_kernel) feeding the recurrence
+// through a 268 MB fp32 stream per layer; here it is formed INSIDE the recurrent workgroup, so that both layers of a stack can run
+// as one layer-pipelined launch (the recurrences of layer 0 and layer 1 overlap on 2 x 128 CUs) and the stream never exists.
+// What made that impossible before is the register file: W_hh hi + lo (128 VGPRs) leave no room for W_ih hi + lo.  Now
+//   * W_ih hi lives in LDS (fragment order, 4H x H bf16 = 128 KB at H = 128: the CU's 160 KB hold it beside the operand images),
+//   * W_ih lo is streamed from L2, one k-step (4 fragments = 16 VGPRs) per time step, issued at the top of the step,
+//   * the projection is formed FOUR STEPS AT A TIME: the 16 MFMA columns carry 4 steps x 4 windows, so a k-step's three products
+//     (hi*hi, lo*hi, hi*lo) cost 12 MFMAs per wave and time step instead of 48 — k-step s of the NEXT group runs during step s of
+//     the current one, off the recurrence's dependency chain;
+//   * the accumulated projection (column 4*s + w = step s, window w) is picked apart with DPP row shifts at its step: cell lane
+//     (q, jj) takes register jj >> 2 of lane (q, 4*s + (jj & 3)).
+// The MFMA sequence per output element (k-step major, products hi*hi, lo*hi, hi*lo, bias added last) is that of xproj_sp_kernel,
+// and the recurrent part is that of lstm_fwd_sp_body<MODE 0>, so the results are BIT-IDENTICAL to the two-launch form
+// (tests/test_gpu_vae.py::test_split_pair_launch_is_bit_identical).
+// Input hand-off: the layer below (lstm_fwd_sp_body<..., PRODUCE>) stores its h planes with sc1 stores and publishes its progress;
+// this workgroup polls that word and reads the planes ONLY with sc1 buffer loads, one 16-byte load per thread and group of 4 steps.
+template <int S> __device__ __forceinline__ float xsel(const f32x4 x) {
+    // dest lane jj of each 16-lane row <- register jj >> 2 of lane 4*S + (jj & 3): bank r (lanes 4r..4r+3) reads lanes 4S..4S+3
+    auto mv = [](int old, float src, auto rc) {
+        constexpr int R = decltype(rc)::value;
+        constexpr int ctrl = R > S ? 0x110 + 4 * (R - S) : (R < S ? 0x100 + 4 * (S - R) : 0xE4);   // row_shr / row_shl / identity quad_perm
+        return __builtin_amdgcn_update_dpp(old, __float_as_int(src), ctrl, 0xF, 1 << R, false);
+    };
+    int v = 0;
+    v = mv(v, x[0], std::integral_constant<int, 0>{});
+    v = mv(v, x[1], std::integral_constant<int, 1>{});
+    v = mv(v, x[2], std::integral_constant<int, 2>{});
+    v = mv(v, x[3], std::integral_constant<int, 3>{});
+    return __int_as_float(v);
+}
+
+template <int H, bool DROP, bool SAVE>
+__device__ __forceinline__ void lstm_fwd_sp_fused(const LstmFwdArgsS& a, const int tile, gu32* flag_in, gu32* err) {
+    constexpr int NW = H / 16, NTHR = 64 * NW;
+    constexpr int KSH = H / 32, KQH = H / 4, RSH = lds_row_stride(KQH);
+    constexpr int HBUF = 4 * 16 * RSH;                 // bf16 elements of one operand image (16 rows x H, quarter-major)
+    constexpr int WLDS = 4 * H * H;                    // W_ih hi, fragment order [wave][k-step][gate][lane][8]
+    static_assert(KSH <= 4, "one k-step of the projection per time step of a 4-step group");
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem_b[];
+    bf16_t* w_lds = smem_b;                            // W_ih fp16 part
+    bf16_t* h_lds = smem_b + WLDS;                     // [2][HBUF]   rows 0..3 hi, 4..7 lo
+    f16_t* x_lds = reinterpret_cast<f16_t*>(h_lds + 2 * HBUF);       // [2 planes][HBUF] f16 hi / lo; row 4*s + w = step s of the group, window w
+    unsigned char* x8_lds = reinterpret_cast<unsigned char*>(x_lds + 2 * HBUF);   // [HBUF] bytes: e4m3(x), same geometry
+    float* b_lds = reinterpret_cast<float*>(x8_lds + HBUF);          // [4H] b_ih + b_hh: read back once per group (a global load there would
+                                                                      // wait, in order, behind every record store still in flight)
+
+    const int T = a.T, B = a.B;
+    const int NG = (T + 3) >> 2;                       // groups of 4 steps
+    const int tid = threadIdx.x, lane = tid & 63, ht = tid >> 6, q = lane >> 4, j = lane & 15;
+    const int cj = j & 3, cr = j >> 2, cu = ht * 16 + q * 4 + cr;
+    const int cb = tile * WPT + cj;
+    const bool cvalid = cb < B;
+
+    for (int e = tid; e < 4 * HBUF + HBUF / 2; e += NTHR) h_lds[e] = (bf16_t)0.f;      // both h images, the two f16 x images, the byte image
+
+    bf16x8 whi[4][KSH], wlo[4][KSH];
+    {
+        const size_t off = (size_t)ht * KSH * 4 * 64 + lane;
+        const bf16x8* ph = reinterpret_cast<const bf16x8*>(a.Wh_hi) + off;
+        const bf16x8* pl = reinterpret_cast<const bf16x8*>(a.Wh_lo) + off;
+#pragma unroll
+        for (int s = 0; s < KSH; ++s)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { whi[g][s] = ph[(s * 4 + g) * 64]; wlo[g][s] = pl[(s * 4 + g) * 64]; }
+    }
+    // W_ih: this wave's fragments; the fp16 part -> LDS (read back only by this wave), the fp8 residual -> registers (2 per fragment)
+    const size_t wfrag = (size_t)ht * KSH * 4 * 64 + lane;
+    f16x8* const wx_lds = reinterpret_cast<f16x8*>(w_lds) + wfrag;
+    long wx8[4][KSH];
+    {
+        const f16x8* px = reinterpret_cast<const f16x8*>(a.Wx_hi) + wfrag;
+        const long* p8 = reinterpret_cast<const long*>(a.Wx_lo) + wfrag;
+#pragma unroll
+        for (int i = 0; i < KSH * 4; ++i) wx_lds[i * 64] = px[i * 64];
+#pragma unroll
+        for (int s = 0; s < KSH; ++s)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { wx8[g][s] = p8[(s * 4 + g) * 64]; asm volatile("" : "+v"(wx8[g][s])); }   // opaque: a loop-invariant load the
+    }                                                                                                                     // compiler would re-issue inside the loop
+    for (int e = tid; e < 4 * H; e += NTHR) b_lds[e] = a.bias[e];
+    const float* const bias_p = b_lds + ht * 16 + q * 4;
+
+    const int my_h_off = ((cu / KQH) * 16 + cj) * RSH + (cu % KQH);
+    constexpr int NCH = WPT * H / 8;
+    static_assert(2 * NCH <= NTHR, "one chunk per thread");
+    const int fpl = tid >= NCH ? 1 : 0, fc = tid < 2 * NCH ? tid - fpl * NCH : 0;
+    const int fjj = fc / (H / 8), fc8 = (fc - fjj * (H / 8)) * 8;
+    const int f_img_off = ((fc8 / KQH) * 16 + fjj + 4 * fpl) * RSH + (fc8 % KQH);
+    // global streams of this workgroup go through buffer descriptors (SGPRs) + 32-bit offsets: 64-bit pointers per stream cost the
+    // registers this kernel does not have
+    const uint32_t seq_bytes = (uint32_t)T * WPT * H * 2;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const __amdgpu_buffer_rsrc_t out_hi = make_rsrc(a.h_hi + (size_t)tile * T * WPT * H, seq_bytes);
+    const __amdgpu_buffer_rsrc_t out_lo = make_rsrc(a.h_lo + (size_t)tile * T * WPT * H, seq_bytes);
+    bf16_t* const f_dst = (fpl ? a.h_lo : a.h_hi) + (size_t)tile * T * WPT * H + (size_t)fc * 8;
+    auto h_flush = [&](int t_done, int buf) {
+        if constexpr (NCH % 64 == 0) {                 // the plane is wave-uniform: descriptor path
+            if (tid < 2 * NCH) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(h_lds + buf * HBUF + f_img_off);
+                if (wv >= NCH / 64) __builtin_amdgcn_raw_buffer_store_b128(v, out_lo, (uint32_t)fc * 16, (uint32_t)t_done * WPT * H * 2, 0);
+                else __builtin_amdgcn_raw_buffer_store_b128(v, out_hi, (uint32_t)fc * 16, (uint32_t)t_done * WPT * H * 2, 0);
+            }
+        } else if (tid < 2 * NCH)
+            *reinterpret_cast<bf16x8*>(f_dst + (size_t)t_done * WPT * H) = *reinterpret_cast<const bf16x8*>(h_lds + buf * HBUF + f_img_off);
+    };
+
+    // ---- staging of the layer input, a group of 4 steps (16 tile-blocked rows x H, contiguous in both planes) at a time.
+    // No dropout: thread c < 2 CHP moves chunk c % CHP of plane c / CHP (wave-uniform).  Dropout: thread c < CHP needs both planes of
+    // its chunk (mask on hi + lo, rescale, split again) and also keeps the masked planes for the dW_ih GEMM.
+    // thread c < 2 CHP takes HALF a 16-byte chunk (4 elements) of BOTH planes: the conversion needs hi + lo of an element in one thread
+    constexpr int CHP = 16 * H / 8;
+    static_assert(2 * CHP <= NTHR, "one half chunk per thread");
+    const int sc = (tid >> 1) % CHP, sjj = sc / (H / 8);
+    const int sc8 = (sc - sjj * (H / 8)) * 8 + 4 * (tid & 1);
+    const int s_img = ((sc8 / KQH) * 16 + sjj) * RSH + (sc8 % KQH);
+    const bool stager = tid < 2 * CHP;
+    const __amdgpu_buffer_rsrc_t in_hi = make_rsrc(a.in_hi + (size_t)tile * T * WPT * H, seq_bytes);
+    const __amdgpu_buffer_rsrc_t in_lo = make_rsrc(a.in_lo + (size_t)tile * T * WPT * H, seq_bytes);
+    const uint32_t thr = drop_threshold(a.drop_p);
+    const float dscale = DROP ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    int avail = 0;                                     // wave-uniform: producer steps < avail are in memory
+    auto wait_for = [&](int need) {
+        if (avail >= need) return;
+        unsigned v, spins = 0;
+#pragma clang loop unroll(disable)
+        for (;;) {
+            v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flag_in, SHM_RLX_AGENT));
+            if ((int)v >= need) break;
+            if (++spins > SPIN_MAX) {                  // give up: finish with garbage, flagged in the err word
+                if (lane == 0) __hip_atomic_store(err, 1u + (unsigned)tile, SHM_RLX_AGENT);
+                v = 0x7fffffff;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        avail = (int)v;
+    };
+    const __amdgpu_buffer_rsrc_t xd_hi = make_rsrc(DROP ? a.xd_hi + (size_t)tile * T * WPT * H : nullptr, DROP ? seq_bytes : 0);
+    const __amdgpu_buffer_rsrc_t xd_lo = make_rsrc(DROP ? a.xd_lo + (size_t)tile * T * WPT * H : nullptr, DROP ? seq_bytes : 0);
+    const uint32_t s_off = (uint32_t)(sjj * H + sc8) * 2;          // this thread's half chunk inside a 16-row group block (bytes)
+    struct Raw { u32x2 h, l; };
+    auto x_fetch = [&](Raw& R, int G) {               // rows of steps 4G .. 4G+3 (rows of steps >= T: out of range, read as zero)
+        if (!stager) return;
+        const int need = 4 * G + 4 < T ? 4 * G + 4 : T;
+        wait_for(need);
+        const uint32_t goff = (uint32_t)(4 * G * WPT * H) * 2;
+        R.h = __builtin_amdgcn_raw_buffer_load_b64(in_hi, s_off, goff, 16);
+        R.l = __builtin_amdgcn_raw_buffer_load_b64(in_lo, s_off, goff, 16);
+    };
+    auto x_commit = [&](Raw& R, int G) {
+        if (!stager) return;
+        const size_t r = ((size_t)tile * T + 4 * G) * WPT + sjj;               // tile-blocked row
+        const XConv cv = x_convert<DROP>(R.h, R.l, a.drop_seed, a.drop_stack, (uint32_t)(r * H + sc8), thr, dscale);
+        *reinterpret_cast<f16x4*>(x_lds + s_img) = cv.hi;
+        *reinterpret_cast<f16x4*>(x_lds + HBUF + s_img) = cv.lo;
+        *reinterpret_cast<unsigned*>(x8_lds + s_img) = cv.x8;
+        if constexpr (DROP) {                          // the masked planes are kept for the dW_ih GEMM (rows of steps >= T: out of range, dropped)
+            const uint32_t goff = (uint32_t)(4 * G * WPT * H) * 2;
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, cv.dh), xd_hi, s_off, goff, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, cv.dl), xd_lo, s_off, goff, 0);
+        }
+    };
+
+    // ---- projection of a whole group in the canonical order (see x_convert): XC[g] = [sum_s W8 x8] 2^-15 + sum_s (W16 xh + W16 xl) + bias.
+    // ONE set of accumulators: the block runs at the LAST step of a group, right after that step has taken its own values out of XC,
+    // beside the cell update's vector work (the MFMAs depend on nothing the step computes).
+    f32x4 XC[4];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto xp_group = [&]() {
+        const int xoff = (q * 16 + j) * RSH;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) XC[g] = zero4;
+#pragma unroll
+        for (int s = 0; s < KSH; ++s) {
+            const long b8 = *reinterpret_cast<const long*>(x8_lds + xoff + 8 * s);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) XC[g] = mfma_fp8_16x16x32(wx8[g][s], b8, XC[g]);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) XC[g] = XC[g] * SHM_W8_UNSCALE;
+        // the fp16 fragments of W_ih come out of LDS one fragment AHEAD of the MFMAs that use them
+        f16x8 wn = wx_lds[0];
+#pragma unroll
+        for (int s = 0; s < KSH; ++s) {
+            const f16x8 bh = *reinterpret_cast<const f16x8*>(x_lds + xoff + 8 * s);
+            const f16x8 bl = *reinterpret_cast<const f16x8*>(x_lds + HBUF + xoff + 8 * s);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f16x8 wh = wn;
+                if (s * 4 + g + 1 < KSH * 4) wn = wx_lds[(s * 4 + g + 1) * 64];
+                XC[g] = mfma_f16_16x16x32(wh, bh, XC[g]);
+                XC[g] = mfma_f16_16x16x32(wh, bl, XC[g]);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) XC[g] = XC[g] + *reinterpret_cast<const f32x4*>(bias_p + g * H);
+    };
+
+    // ---- prologue: group 0 staged and projected
+    {
+        Raw R0;
+        x_fetch(R0, 0);
+        __syncthreads();                               // images zeroed
+        x_commit(R0, 0);
+        __syncthreads();
+        xp_group();
+        __syncthreads();                               // the image is free for group 1
+    }
+
+    float c = 0.f, h = 0.f;
+    // BPTT records: stored at the END of their own step (the two-launch form keeps them across the barrier to store them behind the next
+    // step's MFMA issue: six registers this kernel needs elsewhere)
+    const __amdgpu_buffer_rsrc_t rec4 = make_rsrc(SAVE ? a.rec4 + (size_t)tile * T * NW * 64 * 4 : nullptr, SAVE ? (uint32_t)T * NW * 64 * 16 : 0);
+    const __amdgpu_buffer_rsrc_t rec2 = make_rsrc(SAVE ? a.rec2 + (size_t)tile * T * NW * 64 * 2 : nullptr, SAVE ? (uint32_t)T * NW * 64 * 8 : 0);
+    const uint32_t rec_off = (uint32_t)tid * 16;
+    Raw RX;
+
+    // step S of group G.  S == 0: the rows of group G+1 are requested (sc1 loads); S == 1: they go into the x image (free since the
+    // projection block of the group before); S == 3: group G+1 is projected.
+    auto step = [&](auto sc_, const int G) {
+        constexpr int S = decltype(sc_)::value;
+        const int t = 4 * G + S;
+        const bool more = G + 1 < NG;
+        if (S == 0 && more) x_fetch(RX, G + 1);
+        float gate[4];
+        const int cur = t & 1;
+        if (t < T) {
+            if (t > 0) h_flush(t - 1, cur);
+            f32x4 acc[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = zero4;
+            __builtin_amdgcn_s_setprio(1);
+            {
+                const bf16_t* row = h_lds + cur * HBUF + (q * 16 + j) * RSH;
+#pragma unroll
+                for (int s = 0; s < KSH; ++s) {
+                    const bf16x8 bv = *reinterpret_cast<const bf16x8*>(row + 8 * s);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        acc[g] = mfma_bf16_16x16x32(whi[g][s], bv, acc[g]);
+                        acc[g] = mfma_bf16_16x16x32(wlo[g][s], bv, acc[g]);
+                    }
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gate[g] = redeal_hl(acc[g]) + xsel<S>(XC[g]);
+        }
+        if (S == 3 && more) xp_group();                // XC is dead from here on in this group
+        if (t < T) {
+            constexpr float L2E = 1.4426950408889634f;
+            const float e_i = __builtin_amdgcn_exp2f(-L2E * gate[0]), e_f = __builtin_amdgcn_exp2f(-L2E * gate[1]);
+            const float e_g = __builtin_amdgcn_exp2f(2.0f * L2E * gate[2]), e_o = __builtin_amdgcn_exp2f(-L2E * gate[3]);
+            const float gi = __builtin_amdgcn_rcpf(1.0f + e_i), gf = __builtin_amdgcn_rcpf(1.0f + e_f);
+            const float r_g = __builtin_amdgcn_rcpf(1.0f + e_g), go = __builtin_amdgcn_rcpf(1.0f + e_o);
+            const float gg = 1.0f - 2.0f * r_g;
+            const float c_prev = c;
+            c = gf * c + gi * gg;
+            const float e_c = __builtin_amdgcn_exp2f(2.0f * L2E * c);
+            const float tc = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e_c);
+            h = go * tc;
+            {
+                const bf16x2 s2 = split2(h);
+                bf16_t* hl = h_lds + (cur ^ 1) * HBUF + my_h_off;
+                hl[0] = s2[0]; hl[4 * RSH] = s2[1];
+            }
+            if constexpr (SAVE) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{gi, gf, gg, go}), rec4, rec_off, (uint32_t)t * NW * 64 * 16, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f32x2{c_prev, tc}), rec2, rec_off >> 1, (uint32_t)t * NW * 64 * 8, 0);
+            }
+        }
+        if (S == 1 && more) x_commit(RX, G + 1);
+        __syncthreads();
+    };
+    for (int G = 0; G < NG; ++G) {
+        step(std::integral_constant<int, 0>{}, G);
+        step(std::integral_constant<int, 1>{}, G);
+        step(std::integral_constant<int, 2>{}, G);
+        step(std::integral_constant<int, 3>{}, G);
+    }
+    h_flush(T - 1, T & 1);
+    if (a.h_last && cvalid) a.h_last[(size_t)cb * H + cu] = h;
+}
+
+// Two layers of a stack, one launch (the split-precision twin of lstm_fwd_pair_bf16_kernel).  sync: [0] ticket, flag of tile i at
+// sync[16 * (1 + i)] (a 64-byte line each), all zero at launch: the previous pair launch zeroed it (the plan alternates two blocks;
+// shm_vae_pack_weights zeroes the first); err: the plan's sticky status word.  Roles come from a ticket, not from blockIdx: a consumer
+// only ever waits for a workgroup that drew a smaller ticket, i.e. one that is already running, so the launch cannot deadlock whatever
+// the dispatch order or residency.
+template <int H, int MODE0, bool DROP, bool SAVE>
+__global__ void __launch_bounds__(4 * H) lstm_fwd_pair_sp_kernel(LstmFwdPairArgsS p) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem_b[];
+    gu32* sync = (gu32*)p.sync;
+    const int tiles = gridDim.x >> 1;
+    int* role_lds = reinterpret_cast<int*>(reinterpret_cast<char*>(smem_b) + p.role_lds_off);
+    if (threadIdx.x == 0) *role_lds = (int)__hip_atomic_fetch_add(sync, 1u, SHM_RLX_AGENT);
+    __syncthreads();
+    const int ticket = *role_lds;
+    __syncthreads();
+    const int grp = ticket / (2 * PAIR_GROUP), r = ticket - grp * 2 * PAIR_GROUP, base = grp * PAIR_GROUP;
+    const int ntg = min(PAIR_GROUP, tiles - base);
+    const bool producer = r < ntg;
+    const int tile = base + (producer ? r : r - ntg);
+    if (threadIdx.x == 0 && producer) {                   // nobody touches the other block in this launch
+        p.sync_other[16 * (1 + tile)] = 0u;
+        if (ticket == 0) p.sync_other[0] = 0u;
+    }
+    if (producer) lstm_fwd_sp_body<H, MODE0, SAVE, true>(p.l0, tile, sync + 16 * (1 + tile));
+    else lstm_fwd_sp_fused<H, DROP, SAVE>(p.l1, tile, sync + 16 * (1 + tile), (gu32*)p.err);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -382,24 +773,27 @@ __global__ void __launch_bounds__(4 * H) lstm_bwd_sp_kernel(LstmBwdArgsS a) {
 // ---------------------------------------------------------------------------------------------------------------------
 // xproj: out[row][4H] = W_ih in[row] + b for every tile-blocked row at once (the time-parallel half of the forward), written in
 // the recurrent kernel's CELL ORDER: block (row / 4), wave w, lane (q, r*4 + row % 4) holds f32x4 {i,f,g,o} of unit 16w + 4q + r.
-// Workgroup = H/16 waves; wave w owns units [16w, 16w+16) x 4 gates with its W_ih hi / lo fragments in registers and walks
-// 16-row tiles staged through LDS (hi image, lo image; the forward's operand layout).  Three products per fragment
-// (hi*hi, lo*hi, hi*lo).  Dropout: the inter-layer mask is applied to the input while staging ((hi + lo) * scale, split again)
-// and the masked planes are kept for the dW_ih GEMM.
+// Workgroup = H/16 waves; wave w owns units [16w, 16w+16) x 4 gates with its W_ih fragments (fp16 part + fp8 residual, see x_convert)
+// in registers and walks 16-row tiles staged through LDS as f16 hi / f16 lo / e4m3 images (the forward's operand layout).  The MFMA
+// order is the canonical one of x_convert's comment — the fused layer-1 kernel (lstm_fwd_sp_fused) repeats it bit for bit.
+// Dropout: the inter-layer mask is applied to the input while staging ((hi + lo) * scale) and the masked bf16 planes are kept for
+// the dW_ih GEMM.  Since round 3 this launch only runs for the constant-input decoder layer 0 and when pair launches are off.
 template <int H, bool DROP>
 __global__ void __launch_bounds__(4 * H) xproj_sp_kernel(XprojArgsS a, int tiles_per_wg) {
     constexpr int NW = H / 16, NTHR = 64 * NW, KS = H / 32, KQ = H / 4, RS = lds_row_stride(KQ), IMG = 4 * 16 * RS;
-    __shared__ __attribute__((aligned(16))) bf16_t img[2 * 2 * IMG];      // [buf][plane][IMG]
+    __shared__ __attribute__((aligned(16))) f16_t img[2 * 2 * IMG];       // [buf][plane][IMG]
+    __shared__ __attribute__((aligned(16))) unsigned char img8[2 * IMG];  // [buf][IMG] bytes
     const int tid = threadIdx.x, lane = tid & 63, ht = tid >> 6, q = lane >> 4, j = lane & 15;
-    bf16x8 whi[4][KS], wlo[4][KS];
+    f16x8 whi[4][KS];
+    long w8[4][KS];
     {
         const size_t off = (size_t)ht * KS * 4 * 64 + lane;
 #pragma unroll
         for (int s = 0; s < KS; ++s)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                whi[g][s] = reinterpret_cast<const bf16x8*>(a.W_hi)[off + (s * 4 + g) * 64];
-                wlo[g][s] = reinterpret_cast<const bf16x8*>(a.W_lo)[off + (s * 4 + g) * 64];
+                whi[g][s] = reinterpret_cast<const f16x8*>(a.W_hi)[off + (s * 4 + g) * 64];
+                w8[g][s] = reinterpret_cast<const long*>(a.W_lo)[off + (s * 4 + g) * 64];
             }
     }
     f32x4 bias4[4];
@@ -411,48 +805,31 @@ __global__ void __launch_bounds__(4 * H) xproj_sp_kernel(XprojArgsS a, int tiles
     const int R = a.rows, n_tiles = a.cpt > 0 ? a.n_chunk_tiles : (R + 15) / 16;
     auto gtile = [&](int k) { return a.cpt > 0 ? (k / a.cpt) * a.seq_tiles + a.tile_off + (k % a.cpt) : k; };
     const int t0 = blockIdx.x * tiles_per_wg, t1 = min(n_tiles, t0 + tiles_per_wg);
-    // staging: a 16-row tile = 16 x H bf16 per plane = 2H chunks of 16 B; chunk c of a plane -> (row c / (H/8), cols 8 (c % (H/8)))
-    constexpr int CHP = 16 * H / 8;                       // chunks per plane (= NTHR / 2)
-    static_assert(2 * CHP == NTHR, "one chunk per thread");
-    const int spl = tid >= CHP ? 1 : 0, sc = tid - spl * CHP, sjj = sc / (H / 8), sc8 = (sc - sjj * (H / 8)) * 8;
-    const int s_img = spl * IMG + ((sc8 / KQ) * 16 + sjj) * RS + (sc8 % KQ);
-    const bf16x8 zero8 = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
-    bf16x8 st, st2;                                       // DROP: every thread needs both planes of its chunk (threads < CHP do the work)
+    // staging: a 16-row tile = 16 x H bf16 per plane = CHP chunks of 16 B; thread c takes HALF a chunk (4 elements) of both planes
+    constexpr int CHP = 16 * H / 8;
+    static_assert(2 * CHP == NTHR, "one half chunk per thread");
+    const int sc = tid >> 1, sjj = sc / (H / 8), sc8 = (sc - sjj * (H / 8)) * 8 + 4 * (tid & 1);
+    const int s_img = ((sc8 / KQ) * 16 + sjj) * RS + (sc8 % KQ);
+    u32x2 st_h, st_l;
     auto load_tile = [&](int tl) {
         const int r = gtile(tl) * 16 + sjj;
-        if constexpr (DROP) {
-            st = zero8; st2 = zero8;
-            if (tid < CHP && r < R) {
-                st = *reinterpret_cast<const bf16x8*>(a.in_hi + (size_t)r * H + sc8);
-                st2 = *reinterpret_cast<const bf16x8*>(a.in_lo + (size_t)r * H + sc8);
-            }
-        } else {
-            st = r < R ? *reinterpret_cast<const bf16x8*>((spl ? a.in_lo : a.in_hi) + (size_t)r * H + sc8) : zero8;
+        st_h = u32x2{0u, 0u}; st_l = u32x2{0u, 0u};
+        if (r < R) {
+            st_h = *reinterpret_cast<const u32x2*>(a.in_hi + (size_t)r * H + sc8);
+            st_l = *reinterpret_cast<const u32x2*>(a.in_lo + (size_t)r * H + sc8);
         }
     };
     auto store_tile = [&](int tl, int buf) {
+        const int r = gtile(tl) * 16 + sjj;
+        const XConv cv = x_convert<DROP>(st_h, st_l, a.drop_seed, a.drop_stack, (uint32_t)((size_t)r * H + sc8), thr, dscale);
+        *reinterpret_cast<f16x4*>(img + buf * 2 * IMG + s_img) = cv.hi;
+        *reinterpret_cast<f16x4*>(img + buf * 2 * IMG + IMG + s_img) = cv.lo;
+        *reinterpret_cast<unsigned*>(img8 + buf * IMG + s_img) = cv.x8;
         if constexpr (DROP) {
-            if (tid < CHP) {
-                const int r = gtile(tl) * 16 + sjj;
-                bf16x8 oh, ol;
-                const uint32_t idx = (uint32_t)((size_t)r * H + sc8);     // element index = tile-blocked row * H + unit (host replica: shm_dropout_keep_mask_tiled)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float f = (float)st[e] + (float)st2[e];
-                    const float m = drop_hash(a.drop_seed, a.drop_stack, idx + e) >= thr ? f * dscale : 0.f;
-                    const bf16x2 s = split2(m);
-                    oh[e] = s[0]; ol[e] = s[1];
-                }
-                bf16_t* d = img + buf * 2 * IMG + ((sc8 / KQ) * 16 + sjj) * RS + (sc8 % KQ);
-                *reinterpret_cast<bf16x8*>(d) = oh;
-                *reinterpret_cast<bf16x8*>(d + IMG) = ol;
-                if (r < R) {
-                    *reinterpret_cast<bf16x8*>(a.xd_hi + (size_t)r * H + sc8) = oh;
-                    *reinterpret_cast<bf16x8*>(a.xd_lo + (size_t)r * H + sc8) = ol;
-                }
+            if (r < R) {
+                *reinterpret_cast<bf16x4*>(a.xd_hi + (size_t)r * H + sc8) = cv.dh;
+                *reinterpret_cast<bf16x4*>(a.xd_lo + (size_t)r * H + sc8) = cv.dl;
             }
-        } else {
-            *reinterpret_cast<bf16x8*>(img + buf * 2 * IMG + s_img) = st;
         }
     };
     if (t0 < t1) { load_tile(t0); store_tile(t0, 0); }
@@ -460,19 +837,28 @@ __global__ void __launch_bounds__(4 * H) xproj_sp_kernel(XprojArgsS a, int tiles
     for (int tl = t0; tl < t1; ++tl) {
         const int cur = (tl - t0) & 1;
         if (tl + 1 < t1) load_tile(tl + 1);
-        const bf16_t* rh = img + cur * 2 * IMG + (q * 16 + j) * RS;
+        const int xoff = (q * 16 + j) * RS;
+        const f16_t* rh = img + cur * 2 * IMG + xoff;
+        const unsigned char* r8 = img8 + cur * IMG + xoff;
         f32x4 acc[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(rh + 8 * s);
-            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(rh + IMG + 8 * s);
+            const long b8 = *reinterpret_cast<const long*>(r8 + 8 * s);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = mfma_fp8_16x16x32(w8[g][s], b8, acc[g]);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = acc[g] * SHM_W8_UNSCALE;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const f16x8 bh = *reinterpret_cast<const f16x8*>(rh + 8 * s);
+            const f16x8 bl = *reinterpret_cast<const f16x8*>(rh + IMG + 8 * s);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                acc[g] = mfma_bf16_16x16x32(whi[g][s], bh, acc[g]);
-                acc[g] = mfma_bf16_16x16x32(wlo[g][s], bh, acc[g]);
-                acc[g] = mfma_bf16_16x16x32(whi[g][s], bl, acc[g]);
+                acc[g] = mfma_f16_16x16x32(whi[g][s], bh, acc[g]);
+                acc[g] = mfma_f16_16x16x32(whi[g][s], bl, acc[g]);
             }
         }
         const int r = gtile(tl) * 16 + j;                 // accumulator column j = tile row j
@@ -591,6 +977,34 @@ int launch_bwd_h(const LstmBwdArgsS& a, hipStream_t s) {
     return SHM_OK;
 }
 
+template <int H>
+int launch_fwd_pair_h(const LstmFwdPairArgsS& p0, hipStream_t s) {
+    LstmFwdPairArgsS p = p0;
+    const LstmFwdArgsS &a = p.l0, &b = p.l1;
+    const int tiles = ceil_div(a.B, WPT);
+    const bool save = a.rec4 != nullptr, drop = b.drop_p > 0.f;
+    const size_t lds_cons = sizeof(bf16_t) * ((size_t)4 * H * H + 4 * 4 * 16 * lds_row_stride(H / 4)) + 4 * 16 * lds_row_stride(H / 4) + sizeof(float) * 4 * H;
+    const size_t lds_prod = sizeof(bf16_t) * 2 * 4 * 16 * (lds_row_stride(H / 4) + (a.mode == 2 ? lds_row_stride(8) : 0));
+    const size_t lds = lds_cons > lds_prod ? lds_cons : lds_prod;
+    p.role_lds_off = (int)lds;
+    void (*kern)(LstmFwdPairArgsS);
+    if (a.mode == 2) kern = drop ? (save ? lstm_fwd_pair_sp_kernel<H, 2, true, true> : lstm_fwd_pair_sp_kernel<H, 2, true, false>)
+                                 : (save ? lstm_fwd_pair_sp_kernel<H, 2, false, true> : lstm_fwd_pair_sp_kernel<H, 2, false, false>);
+    else kern = drop ? (save ? lstm_fwd_pair_sp_kernel<H, 1, true, true> : lstm_fwd_pair_sp_kernel<H, 1, true, false>)
+                     : (save ? lstm_fwd_pair_sp_kernel<H, 1, false, true> : lstm_fwd_pair_sp_kernel<H, 1, false, false>);
+    // the consumer's images + W_ih hi exceed the default 64 KB of dynamic LDS: raise the limit once per kernel instance
+    static const void* raised[32] = {nullptr};
+    bool done = false;
+    for (const void* k : raised) done = done || k == (const void*)kern;
+    if (!done) {
+        SHM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + 16)));
+        for (auto& k : raised) if (!k) { k = (const void*)kern; break; }
+    }
+    SHM_LAUNCH(kern, dim3(2 * tiles), dim3(4 * H), lds + 16, s, p);
+    SHM_LAUNCH_CHECK();
+    return SHM_OK;
+}
+
 inline int tiles_per_wg_for(int n_tiles) { return n_tiles >= 2048 ? 8 : 1; }
 
 template <int H>
@@ -639,6 +1053,28 @@ int launch_lstm_fwd_sp(int H, const LstmFwdArgsS& a0, hipStream_t s) {
     if (a.mode == 2) SHM_REQUIRE(a.x && a.Wx_hi && a.Wx_lo && a.bias && a.In >= 1 && a.In <= 16, SHM_EINVAL, "lstm_fwd_sp: mode 2 needs x, W_ih, bias and In <= 16 (got %d)", a.In);
     else SHM_REQUIRE(a.xproj && (a.mode == 0 || a.mode == 1), SHM_EINVAL, "lstm_fwd_sp: modes 0/1 need the projected input");
     SHM_DISPATCH_H(launch_fwd_h, "lstm_fwd_sp")
+}
+int launch_lstm_fwd_pair_sp(int H, const LstmFwdPairArgsS& a, hipStream_t s) {
+    const LstmFwdArgsS &l0 = a.l0, &l1 = a.l1;
+    SHM_REQUIRE(l0.B > 0 && l0.T > 0 && l0.B == l1.B && l0.T == l1.T, SHM_EINVAL, "lstm_fwd_pair_sp: empty shape or shape mismatch");
+    SHM_REQUIRE(a.sync && a.sync_other && a.sync != a.sync_other && a.err, SHM_EINVAL, "lstm_fwd_pair_sp: sync blocks or status word missing");
+    SHM_REQUIRE(l0.Wh_hi && l0.Wh_lo && l0.h_hi && l0.h_lo && l1.Wh_hi && l1.Wh_lo && l1.h_hi && l1.h_lo, SHM_EINVAL, "lstm_fwd_pair_sp: packed weights or h planes missing");
+    SHM_REQUIRE((l0.rec4 != nullptr) == (l0.rec2 != nullptr) && (l1.rec4 != nullptr) == (l1.rec2 != nullptr) && (l0.rec4 != nullptr) == (l1.rec4 != nullptr),
+                SHM_EINVAL, "lstm_fwd_pair_sp: both layers save both record planes, or neither");
+    if (l0.mode == 2) SHM_REQUIRE(l0.x && l0.Wx_hi && l0.Wx_lo && l0.bias && l0.In >= 1 && l0.In <= 16, SHM_EINVAL, "lstm_fwd_pair_sp: layer 0 in mode 2 needs x, W_ih, bias and In <= 16 (got %d)", l0.In);
+    else SHM_REQUIRE(l0.mode == 1 && l0.xproj, SHM_EINVAL, "lstm_fwd_pair_sp: layer 0 must be the fp32-input layer (mode 2) or the constant-input layer (mode 1)");
+    SHM_REQUIRE(l1.in_hi == l0.h_hi && l1.in_lo == l0.h_lo && l1.Wx_hi && l1.Wx_lo && l1.bias, SHM_EINVAL, "lstm_fwd_pair_sp: layer 1 must read layer 0's h planes and bring W_ih hi / lo and its bias");
+    SHM_REQUIRE(!(l1.drop_p > 0.f) || (l1.xd_hi && l1.xd_lo), SHM_EINVAL, "lstm_fwd_pair_sp: dropout needs the masked-input planes");
+    SHM_REQUIRE((int64_t)l0.T * WPT * H * 2 < ((int64_t)1 << 31), SHM_EINVAL, "lstm_fwd_pair_sp: T too long for 32-bit buffer offsets");
+    SHM_REQUIRE((l0.t0 == 0 && (l0.t1 == 0 || l0.t1 == l0.T)) && (l1.t0 == 0 && (l1.t1 == 0 || l1.t1 == l1.T)), SHM_EINVAL, "lstm_fwd_pair_sp: whole windows only");
+    LstmFwdPairArgsS p = a;
+    p.l0.t0 = 0; p.l0.t1 = l0.T; p.l1.t0 = 0; p.l1.t1 = l1.T;
+    switch (H) {
+        case 32: return launch_fwd_pair_h<32>(p, s);
+        case 64: return launch_fwd_pair_h<64>(p, s);
+        case 128: return launch_fwd_pair_h<128>(p, s);
+        default: set_error("lstm_fwd_pair_sp: hidden_dim %d unsupported (32, 64, 128)", H); return SHM_EINVAL;
+    }
 }
 int launch_lstm_bwd_sp(int H, const LstmBwdArgsS& a0, hipStream_t s) {
     LstmBwdArgsS a = a0;

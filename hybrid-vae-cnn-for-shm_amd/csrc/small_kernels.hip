@@ -914,6 +914,22 @@ __global__ void __launch_bounds__(256) pack_all_kernel(PackJobs jobs) {
             const int k = (lane >> 4) * H + 8 * s + e, m = mt * 16 + (lane & 15);
             dst[i] = part(m < M ? jb.src[(size_t)k * M + m] : 0.f, jb.kind == 6);
         }
+    } else if (jb.kind == 7 || jb.kind == 8) {     // forward operand as fp16 hi (7) / fp8 residual (8): W ~ fp16(W) + e4m3((W - fp16(W)) 2^15) 2^-15
+        const int K = jb.K, Kp = (K + 31) & ~31, KQ = Kp >> 2, KS = KQ >> 3;
+        for (size_t i = i0; i < (size_t)4 * H * Kp; i += stride) {
+            const int e = i & 7, lane = (i >> 3) & 63;
+            size_t r = i >> 9;
+            const int g = r & 3; r >>= 2;
+            const int s = r % KS, ht = r / KS;
+            const int row = g * H + ht * 16 + (lane & 15), k = (lane >> 4) * KQ + 8 * s + e;
+            const float w = k < K ? jb.src[(size_t)row * K + k] : 0.f;
+            const _Float16 hi = (_Float16)w;
+            if (jb.kind == 7) reinterpret_cast<_Float16*>(jb.dst)[i] = hi;
+            else {
+                const float d = fminf(fmaxf((w - (float)hi) * SHM_W8_SCALE, -SHM_F8_MAX), SHM_F8_MAX);
+                reinterpret_cast<unsigned char*>(jb.dst)[i] = (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(d, 0.f, 0, false) & 0xff);
+            }
+        }
     } else if (jb.kind == 2) {     // bias sum b_ih + b_hh
         float* dst = reinterpret_cast<float*>(jb.dst);
         for (size_t i = i0; i < (size_t)4 * H; i += stride) dst[i] = jb.src[i] + jb.src2[i];

@@ -1,0 +1,115 @@
+"""Split-precision path, layer-pipelined forward (round 3): lstm_fwd_pair_sp_kernel runs both layers of a stack in ONE launch and
+forms layer 1's input projection inside the recurrent workgroup (W_ih hi in LDS, W_ih lo streamed from L2, four steps per MFMA tile).
+Its MFMA sequence per output element is the one of the two-launch form (xproj_sp_kernel + lstm_fwd_sp_kernel), so every result must be
+BIT-IDENTICAL to one launch per layer — which is itself pinned to the reference goldens at 1e-4 (tests/test_gpu_vae.py, split legs).
+Reference arithmetic: 4DOF/Scripts/Models/temporal_vae.py:51-77 (nn.LSTM stacks), 4DOF/Scripts/03_train_vae.py:260-271 (train step)."""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_vae import inject_eps
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = ((512, 256, 128), (510, 100, 128), (37, 50, 64), (9, 31, 32), (1, 1, 128), (3, 2, 128), (5, 3, 64), (2, 5, 32), (4, 7, 128),
+          (6, 9, 128), (7, 12, 64), (1100, 20, 128))        # ragged last tiles, T % 4 != 0, T < one 4-step group, three ticket groups
+
+
+@pytest.mark.parametrize("train_mode", [False, True])
+def test_split_layer_pipelined_forward_is_bit_identical(train_mode):
+    from Scripts.Models.temporal_vae import TemporalVAE
+    from shm_hip._capi import lib
+    from shm_hip.trainer import VAETrainer
+    for (B, T, H) in SHAPES:
+        torch.manual_seed(11)
+        m = TemporalVAE(4, 16, H, 2, 0.3, precision="split").cuda()
+        gen = torch.Generator().manual_seed(B)
+        x = torch.randn(B, T, 4, generator=gen).cuda()
+        eps = torch.randn(B, 16, generator=gen).cuda()
+        ref = None
+        for on in (0, 1, 1, 1):
+            lib.shm_set_pair_launch(on)
+            try:
+                if train_mode:
+                    torch.manual_seed(11)
+                    m2 = TemporalVAE(4, 16, H, 2, 0.3, precision="split").cuda().train()
+                    tr = VAETrainer(m2, lr=1e-3, weight_decay=1e-5, max_norm=2.0)
+                    stats = tr.step(x, 0.3, eps=eps, drop_seed=99)
+                    out = (stats.clone(), tr.grads.clone())
+                    tr.engine.check_status()
+                else:
+                    m.eval()
+                    with torch.no_grad(), inject_eps([eps.cpu()]):
+                        out = m(x)
+                    m._engine.check_status()
+            finally:
+                lib.shm_set_pair_launch(1)
+            if ref is None:
+                ref = out
+            else:
+                for a, b in zip(ref, out):
+                    assert torch.equal(a, b), (B, T, H, on, float((a - b).abs().max()))
+
+
+def test_split_pipelined_forward_without_dropout_matches_too():
+    """dropout = 0 takes the staging path that moves whole 16-byte chunks per plane (the dropout path moves half chunks of both planes)."""
+    from Scripts.Models.temporal_vae import TemporalVAE
+    from shm_hip._capi import lib
+    from shm_hip.trainer import VAETrainer
+    for (B, T, H) in ((64, 40, 128), (10, 23, 64), (5, 8, 32)):
+        gen = torch.Generator().manual_seed(7 * B)
+        x = torch.randn(B, T, 4, generator=gen).cuda()
+        eps = torch.randn(B, 16, generator=gen).cuda()
+        ref = None
+        for on in (0, 1, 1):
+            lib.shm_set_pair_launch(on)
+            try:
+                torch.manual_seed(3)
+                m = TemporalVAE(4, 16, H, 2, 0.0, precision="split").cuda().train()
+                tr = VAETrainer(m, lr=1e-3, weight_decay=1e-5, max_norm=2.0)
+                out = (tr.step(x, 0.3, eps=eps).clone(), tr.grads.clone())
+                tr.engine.check_status()
+            finally:
+                lib.shm_set_pair_launch(1)
+            if ref is None:
+                ref = out
+            else:
+                for a, b in zip(ref, out):
+                    assert torch.equal(a, b), (B, T, H, float((a - b).abs().max()))
+
+
+def test_split_pipelined_handoff_under_memory_load():
+    """The in-launch hand-off must not depend on timing: repeat the pipelined train step while a second stream streams 512 MB copies
+    through HBM / L2 (uneven load on the CUs' memory queues) and require bit-identity with the one-launch-per-layer result every time."""
+    from Scripts.Models.temporal_vae import TemporalVAE
+    from shm_hip._capi import lib
+    from shm_hip.trainer import VAETrainer
+    B, T, H = 512, 128, 128
+    gen = torch.Generator().manual_seed(77)
+    x = torch.randn(B, T, 4, generator=gen).cuda()
+    eps = torch.randn(B, 16, generator=gen).cuda()
+
+    def one(on):
+        lib.shm_set_pair_launch(on)
+        try:
+            torch.manual_seed(21)
+            m = TemporalVAE(4, 16, H, 2, 0.3, precision="split").cuda().train()
+            tr = VAETrainer(m, lr=1e-3, weight_decay=1e-5, max_norm=2.0)
+            st = tr.step(x, 0.3, eps=eps, drop_seed=5).clone()
+            tr.engine.check_status()
+            return st, tr.grads.clone()
+        finally:
+            lib.shm_set_pair_launch(1)
+
+    ref = one(0)
+    side = torch.cuda.Stream()
+    a = torch.empty(128 * 1024 * 1024, dtype=torch.float32, device="cuda")      # 512 MB
+    b = torch.empty_like(a)
+    for rep in range(10):
+        with torch.cuda.stream(side):
+            for _ in range(3 + rep % 4):
+                b.copy_(a, non_blocking=True)
+        got = one(1)
+        side.synchronize()
+        for u, v in zip(ref, got):
+            assert torch.equal(u, v), (rep, float((u - v).abs().max()))
