@@ -42,15 +42,18 @@ __device__ __forceinline__ bf16x2 split2(float v) {
 // accumulator lanes (q, j, r) -> cell lanes (q, jj): the cell of lane jj = (window jj & 3, register jj >> 2) is
 // acc[jj >> 2] of lane jj & 3 (hi columns) + acc[jj >> 2] of lane 4 + (jj & 3) (lo columns); 6 DPP moves + 1 add.
 __device__ __forceinline__ float redeal_hl(const f32x4 a) {
-    int v = __float_as_int(a[0]);
-    v = __builtin_amdgcn_update_dpp(v, __float_as_int(a[1]), 0x114, 0xF, 0x2, false);   // row_shr:4  -> lanes 4..7   (from 0..3)
-    v = __builtin_amdgcn_update_dpp(v, __float_as_int(a[2]), 0x118, 0xF, 0x4, false);   // row_shr:8  -> lanes 8..11  (from 0..3)
-    v = __builtin_amdgcn_update_dpp(v, __float_as_int(a[3]), 0x11C, 0xF, 0x8, false);   // row_shr:12 -> lanes 12..15 (from 0..3)
-    int w = __float_as_int(a[1]);                                                        // lanes 4..7 keep their own register 1
-    w = __builtin_amdgcn_update_dpp(w, __float_as_int(a[0]), 0x104, 0xF, 0x1, false);   // row_shl:4  -> lanes 0..3   (from 4..7)
-    w = __builtin_amdgcn_update_dpp(w, __float_as_int(a[2]), 0x114, 0xF, 0x4, false);   // row_shr:4  -> lanes 8..11  (from 4..7)
-    w = __builtin_amdgcn_update_dpp(w, __float_as_int(a[3]), 0x118, 0xF, 0x8, false);   // row_shr:8  -> lanes 12..15 (from 4..7)
-    return __int_as_float(v) + __int_as_float(w);
+    // hi + lo first, in accumulator layout (lane j < 4 adds its own register to that of lane j + 4: one VALU add with a DPP source each),
+    // then the three moves that deal registers 1..3 to lanes 4..15.  Same two addends per cell as gathering hi and lo separately
+    // (6 moves + 1 add), so the sum is bit-identical; 7 vector instructions per gate instead of 9.
+    float s[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        s[r] = a[r] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a[r]), 0x104, 0xF, 0xF, true));   // row_shl:4
+    int v = __float_as_int(s[0]);
+    v = __builtin_amdgcn_update_dpp(v, __float_as_int(s[1]), 0x114, 0xF, 0x2, false);   // row_shr:4  -> lanes 4..7
+    v = __builtin_amdgcn_update_dpp(v, __float_as_int(s[2]), 0x118, 0xF, 0x4, false);   // row_shr:8  -> lanes 8..11
+    v = __builtin_amdgcn_update_dpp(v, __float_as_int(s[3]), 0x11C, 0xF, 0x8, false);   // row_shr:12 -> lanes 12..15
+    return __int_as_float(v);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -429,11 +432,10 @@ __device__ __forceinline__ void lstm_fwd_sp_fused(const LstmFwdArgsS& a, const i
     // its chunk (mask on hi + lo, rescale, split again) and also keeps the masked planes for the dW_ih GEMM.
     // thread c < 2 CHP takes HALF a 16-byte chunk (4 elements) of BOTH planes: the conversion needs hi + lo of an element in one thread
     constexpr int CHP = 16 * H / 8;
-    static_assert(2 * CHP <= NTHR, "one half chunk per thread");
+    static_assert(2 * CHP == NTHR, "one half chunk per thread, every thread stages");
     const int sc = (tid >> 1) % CHP, sjj = sc / (H / 8);
     const int sc8 = (sc - sjj * (H / 8)) * 8 + 4 * (tid & 1);
     const int s_img = ((sc8 / KQH) * 16 + sjj) * RSH + (sc8 % KQH);
-    const bool stager = tid < 2 * CHP;
     const __amdgpu_buffer_rsrc_t in_hi = make_rsrc(a.in_hi + (size_t)tile * T * WPT * H, seq_bytes);
     const __amdgpu_buffer_rsrc_t in_lo = make_rsrc(a.in_lo + (size_t)tile * T * WPT * H, seq_bytes);
     const uint32_t thr = drop_threshold(a.drop_p);
@@ -460,15 +462,23 @@ __device__ __forceinline__ void lstm_fwd_sp_fused(const LstmFwdArgsS& a, const i
     const uint32_t s_off = (uint32_t)(sjj * H + sc8) * 2;          // this thread's half chunk inside a 16-row group block (bytes)
     struct Raw { u32x2 h, l; };
     auto x_fetch = [&](Raw& R, int G) {               // rows of steps 4G .. 4G+3 (rows of steps >= T: out of range, read as zero)
-        if (!stager) return;
-        const int need = 4 * G + 4 < T ? 4 * G + 4 : T;
+        const int need = G >= NG ? 0 : (4 * G + 4 < T ? 4 * G + 4 : T);       // G == NG: a fetch of nothing (see step)
         wait_for(need);
         const uint32_t goff = (uint32_t)(4 * G * WPT * H) * 2;
-        R.h = __builtin_amdgcn_raw_buffer_load_b64(in_hi, s_off, goff, 16);
-        R.l = __builtin_amdgcn_raw_buffer_load_b64(in_lo, s_off, goff, 16);
+        // inline asm: the compiler does not track these two loads, so it cannot put its own (uncounted: the step bodies branch) vmcnt(0) in
+        // front of their first use — x_ready() below waits with the count this kernel knows
+        asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen sc1" : "=v"(R.h) : "v"(s_off), "s"(in_hi), "s"(goff) : "memory");
+        asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen sc1" : "=v"(R.l) : "v"(s_off), "s"(in_lo), "s"(goff) : "memory");
     };
-    auto x_commit = [&](Raw& R, int G) {
-        if (!stager) return;
+    // Every wave issues, after the two loads of x_fetch (top of step S = 0) and before their use (step S = 1), at least its two record
+    // stores (SAVE) — waves 0 and 1 also an h-plane store.  vmcnt retires in order, so "at most 2 outstanding" covers the loads without
+    // waiting for the record stores just issued (the compiler's own wait here was vmcnt(0): the stores' round trip, once per group).
+    auto x_ready = [&](Raw& R, bool in_loop) {
+        if (SAVE && in_loop) asm volatile("s_waitcnt vmcnt(2)" : "+v"(R.h), "+v"(R.l) : : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(R.h), "+v"(R.l) : : "memory");
+    };
+    auto x_commit = [&](Raw& R, int G, bool in_loop = true) {
+        x_ready(R, in_loop);
         const size_t r = ((size_t)tile * T + 4 * G) * WPT + sjj;               // tile-blocked row
         const XConv cv = x_convert<DROP>(R.h, R.l, a.drop_seed, a.drop_stack, (uint32_t)(r * H + sc8), thr, dscale);
         *reinterpret_cast<f16x4*>(x_lds + s_img) = cv.hi;
@@ -521,7 +531,7 @@ __device__ __forceinline__ void lstm_fwd_sp_fused(const LstmFwdArgsS& a, const i
         Raw R0;
         x_fetch(R0, 0);
         __syncthreads();                               // images zeroed
-        x_commit(R0, 0);
+        x_commit(R0, 0, false);
         __syncthreads();
         xp_group();
         __syncthreads();                               // the image is free for group 1
@@ -541,7 +551,10 @@ __device__ __forceinline__ void lstm_fwd_sp_fused(const LstmFwdArgsS& a, const i
         constexpr int S = decltype(sc_)::value;
         const int t = 4 * G + S;
         const bool more = G + 1 < NG;
-        if (S == 0 && more) x_fetch(RX, G + 1);
+        // unconditional (behind the last group: all rows out of range, nothing waited for): a fetch under `if (more)` makes RX a merge of
+        // two definitions, and the copy the compiler then inserts would read the destination of a load it does not know is pending
+        // (tools/lint_pending_loads.py checks the assembly for exactly that)
+        if (S == 0) x_fetch(RX, G + 1);
         float gate[4];
         const int cur = t & 1;
         if (t < T) {
@@ -549,25 +562,42 @@ __device__ __forceinline__ void lstm_fwd_sp_fused(const LstmFwdArgsS& a, const i
             f32x4 acc[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) acc[g] = zero4;
-            __builtin_amdgcn_s_setprio(1);
+            // The recurrent MFMAs are issued with the step's h-independent vector work BETWEEN them (it runs in the matrix pipe's shadow):
+            // this step's values picked out of XC, and at S == 1 the conversion of the next group's input rows.  A wave issues in order:
+            // placed behind the MFMA block that work would wait for the pipe, in front of the barrier it delays every wave's arrival.
+            bf16x8 bv[KSH];                            // the whole operand row up front: one LDS latency, not one per k-step
             {
                 const bf16_t* row = h_lds + cur * HBUF + (q * 16 + j) * RSH;
 #pragma unroll
-                for (int s = 0; s < KSH; ++s) {
-                    const bf16x8 bv = *reinterpret_cast<const bf16x8*>(row + 8 * s);
+                for (int s = 0; s < KSH; ++s) bv[s] = *reinterpret_cast<const bf16x8*>(row + 8 * s);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        acc[g] = mfma_bf16_16x16x32(whi[g][s], bv, acc[g]);
-                        acc[g] = mfma_bf16_16x16x32(wlo[g][s], bv, acc[g]);
-                    }
+            for (int s = 0; s < KSH; ++s) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    acc[g] = mfma_bf16_16x16x32(whi[g][s], bv[s], acc[g]);
+                    acc[g] = mfma_bf16_16x16x32(wlo[g][s], bv[s], acc[g]);
                 }
             }
-            __builtin_amdgcn_s_setprio(0);
+            float xs[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) gate[g] = redeal_hl(acc[g]) + xsel<S>(XC[g]);
-        }
-        if (S == 3 && more) xp_group();                // XC is dead from here on in this group
-        if (t < T) {
+            for (int g = 0; g < 4; ++g) xs[g] = xsel<S>(XC[g]);
+            // (no branch on `more` here: one basic block, or the interleave below does not apply.  Without a next group RX is stale, the image
+            // it lands in is never read and the masked-plane stores are out of range, i.e. dropped)
+            if (S == 1) x_commit(RX, G + 1);
+#pragma unroll
+            for (int i = 0; i < 8 * KSH; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA ...
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);     // ... two vector instructions
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gate[g] = redeal_hl(acc[g]) + xs[g];
+        }                                              // (t >= T only happens in the last group: nothing left to stage)
+        auto cell = [&]() {
             constexpr float L2E = 1.4426950408889634f;
             const float e_i = __builtin_amdgcn_exp2f(-L2E * gate[0]), e_f = __builtin_amdgcn_exp2f(-L2E * gate[1]);
             const float e_g = __builtin_amdgcn_exp2f(2.0f * L2E * gate[2]), e_o = __builtin_amdgcn_exp2f(-L2E * gate[3]);
@@ -588,8 +618,20 @@ __device__ __forceinline__ void lstm_fwd_sp_fused(const LstmFwdArgsS& a, const i
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{gi, gf, gg, go}), rec4, rec_off, (uint32_t)t * NW * 64 * 16, 0);
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f32x2{c_prev, tc}), rec2, rec_off >> 1, (uint32_t)t * NW * 64 * 8, 0);
             }
-        }
-        if (S == 1 && more) x_commit(RX, G + 1);
+        };
+        if (S == 3 && more) {                          // XC is dead from here on in this group: the next group's projection, with the cell
+            if (t < T) {                               // update's vector work between its MFMAs
+                __builtin_amdgcn_sched_barrier(0);
+                xp_group();
+                cell();
+#pragma unroll
+                for (int i = 0; i < 12 * KSH; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            } else xp_group();
+        } else if (t < T) cell();
         __syncthreads();
     };
     for (int G = 0; G < NG; ++G) {
