@@ -847,7 +847,15 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
         SHM_HIP_CHECK(hipEventRecord(p->ev_fork, s));
         SHM_HIP_CHECK(hipStreamWaitEvent(gs, p->ev_fork, 0));
     }
-    const int NCb = use_side ? sp_chunks(p, true) : 1;
+    // SHM_SP_BWD_CHUNKS=N: launch-level chunk pipeline for the BACKWARD only (the forward keeps its pair launch): a measurement knob
+    int NCb = use_side ? sp_chunks(p, true) : 1;
+    if (use_side && L == 2) {
+        const char* eb = getenv("SHM_SP_BWD_CHUNKS");
+        int want = eb ? atoi(eb) : 1;
+        if (want > 8) want = 8;
+        while (want > 1 && (T % (4 * want) != 0 || T / want < 16)) --want;
+        if (want > 1) NCb = want;
+    }
     // wide products on bf16 operands: dW_ih = dpre^T x_in (dropout re-applied) and dW_hh = dpre^T h_{t-1} in ONE launch (A read once)
     // lo planes of the split path: {A, Bin, Bh, Bx}
     struct LoPlanes { const void* A; const void* Bin; const void* Bh; const void* Bx; };
