@@ -66,8 +66,8 @@ def kernel_alg_flops(name, B, path="fp32"):
     return 0
 
 
-PMC_SUMMARIES = {"bf16": ROOT / "profiles" / "r02_bf16_pmc_traffic.json", "split": ROOT / "profiles" / "r02_split_pmc_traffic.json",
-                 "cnn": ROOT / "profiles" / "r02_cnn_pmc_traffic.json"}
+PMC_SUMMARIES = {"bf16": ROOT / "profiles" / "r03_bf16_pmc_traffic.json", "split": ROOT / "profiles" / "r03_split_pmc_traffic.json",
+                 "cnn": ROOT / "profiles" / "r03_cnn_pmc_traffic.json"}
 
 # substrings of the demangled kernel names in the PMC summaries, per profile label
 PMC_KERNELS = {

@@ -323,6 +323,7 @@ extern "C" int shm_vae_plan_create(const shm_vae_config* cfg, int32_t B, int32_t
             if (eb2 > eb) eb = eb2;
             p->gemm_partial_b = take(eb > 0 ? eb : 1);
         }
+        if (sp) p->gemm_partial_b = take(gp > 0 ? gp : 1);      // split path: the LAST layer's products run on the caller's stream beside the side stream's (own scratch)
         if (bf) {        // the fp32 dec0 dW_ih GEMM's own split-K scratch (pair path and split path batch it with the layer's other reductions)
             const size_t ec = gemm_tn_partial_elems(B, 4 * H, H);
             p->gemm_partial_c = take(ec > 0 ? ec : 1);
@@ -900,6 +901,10 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
 
     // split path: weight-gradient products waiting to be enqueued on the side stream (see run_stack_bwd)
     std::vector<std::function<int()>> deferred;
+    // final_flush: the last layer of the backward (encoder layer 0) has no recurrence left to hide behind — its products go to the CALLER's
+    // stream (own split-K scratch), so they fill the CUs the last recurrence has just vacated while the side stream is still finishing the
+    // layer before (round 3: the step ended with the main stream idle for ~0.29 ms behind two serial side-stream GEMMs)
+    bool final_flush = false;
     auto flush_deferred = [&]() -> int {
         for (auto& f : deferred) { const int r = f(); if (r) { deferred.clear(); return r; } }
         deferred.clear();
@@ -963,9 +968,13 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
             bf16_t* dph = at<bf16_t>(ws, p->dpre_set[set]); bf16_t* dpl = at<bf16_t>(ws, p->dpre_set_lo[set]);
             float* tsum = at<float>(ws, p->dpre_set_tsum[set]);
             const LayerInst* stp = st;
-            deferred.push_back([=, &gemm_bf, &gemm]() -> int {
+            deferred.push_back([=, &gemm_bf, &gemm, &gs, &final_flush]() -> int {
                 int r2;
-                if (ev) SHM_HIP_CHECK(hipStreamWaitEvent(gs, ev, 0));
+                const hipStream_t side_stream = gs;
+                struct Restore { hipStream_t& g; hipStream_t v; ~Restore() { g = v; } } restore{gs, side_stream};
+                const bool on_main = final_flush && gs != s;
+                if (on_main) gs = s;                                   // gemm_bf / gemm launch on gs
+                else if (ev) SHM_HIP_CHECK(hipStreamWaitEvent(gs, ev, 0));
                 char gnm[32];
                 snprintf(gnm, sizeof(gnm), "dw_gemm.%s%d", sn, l);
                 KernelTimer kt(gnm, gs);
@@ -974,7 +983,7 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
                 // every split-K / per-window reduction of this layer in ONE launch behind its products (was three or four small launches)
                 ReduceJobs rj;
                 rj.n = 0;
-                float* part = at<float>(ws, p->gemm_partial);      // one layer at a time on gs: reduced below before the next product starts
+                float* part = at<float>(ws, on_main ? p->gemm_partial_b : p->gemm_partial);      // one layer at a time per stream: reduced below before the next product starts
                 if (l > 0) {
                     const bool dr = drop > 0.f;
                     const void* xin = dr ? at<char>(ws, stp[l].xdrop) : at<char>(ws, stp[l - 1].h_seq);
@@ -1195,6 +1204,7 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
 
     kt_head.~KernelTimer(); kt_head.idx = -1;
     if ((rc = run_stack_bwd(p->enc, 0, x, false))) return rc;
+    final_flush = use_side && !getenv("SHM_SP_TAIL_ON_SIDE");
     if ((rc = flush_deferred())) return rc;
     if (use_side) {                                          // join: everything after this call on s sees the complete gradient bucket
         SHM_HIP_CHECK(hipEventRecord(p->ev_join, gs));
