@@ -346,6 +346,196 @@ __global__ void __launch_bounds__(512) gemm_tn_bf16_v2_kernel(GemmTnArgsB a, int
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// v3 (round 3) — the split-precision operands of the H = 128 shape: C = A_hi^T B_hi + A_hi^T B_lo + A_lo^T B_hi.
+// v2 serves them by walking its rows three times (plane pairs of a 64-row chunk back to back, the re-reads out of L2): three stages,
+// three barriers, three rounds of LDS-DMA issue and of fragment reads per 32 rows — and that per-stage overhead, not HBM, is what bounds
+// it (0.19 ms alone for 403 MB).  Here ONE stage holds all four planes of its 32 rows (A_hi | A_lo | B_hi | B_lo [| X_hi | X_lo]); the
+// three products run from that image: per 32 rows one barrier, 8 (not 12) LDS-DMA instructions per wave, 24 (not 36) fragment pairs, the
+// same 96 MFMAs.  A stage is 64 KB at NB = 2 (two ring slots, one stage in flight while one is consumed) and 50 KB at NB = 1 (three).
+// Same swizzle, same zero line, same split-K as v2.  Products are summed per stage (hi*hi, hi*lo, lo*hi), v2 summed them per 64-row chunk:
+// results agree to fp32 rounding, not bit for bit.
+template <int NB, bool XP>
+__global__ void __launch_bounds__(512) gemm_tn_sp_v3_kernel(GemmTnArgsB a, int tiles_m, int rows_per_split, int nsplit) {
+    constexpr int NT = 128 * NB;
+    constexpr int A_BYTES = V2_KC * V2_MT * 2, B_BYTES = V2_KC * NT * 2, X_BYTES = XP ? V2_KC * 16 * 2 : 0;
+    constexpr int OFF_ALO = A_BYTES, OFF_BHI = 2 * A_BYTES, OFF_BLO = 2 * A_BYTES + B_BYTES, OFF_XHI = 2 * A_BYTES + 2 * B_BYTES, OFF_XLO = OFF_XHI + X_BYTES;
+    constexpr int ST_BYTES = 2 * (A_BYTES + B_BYTES + X_BYTES);
+    constexpr int NBUF = NB == 2 ? 2 : 3;
+    constexpr int GL_A = 2, GL_B = NB;
+    constexpr int NJ = 2 * NB;
+    constexpr int PS = 2 * (GL_A + GL_B);                // LDS-DMA instructions per wave and stage (wave 0 of an XP launch: + 2)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3, i16 = lane & 15;
+    const int wm = w >> 2, wn = w & 3;
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int tm = local % tiles_m, split = (local / tiles_m) * 8 + xcd;
+    if (split >= nsplit) return;
+    const int m0 = tm * V2_MT;
+    const int r_begin = split * rows_per_split, r_end = min(a.R, r_begin + rows_per_split);
+    const int nst = (r_end - r_begin + V2_KC - 1) / V2_KC;
+    const bf16_t* zeros = reinterpret_cast<const bf16_t*>(a.zeros);
+
+    int a_row[GL_A], a_col[GL_A];
+#pragma unroll
+    for (int i = 0; i < GL_A; ++i) {
+        const int rs = 2 * (2 * w + i) + (lane >> 5), c = lane & 31;
+        a_row[i] = rs; a_col[i] = (((c >> 1) ^ v2_swz(rs)) << 1 | (c & 1)) * 8;
+    }
+    int b_row[GL_B], b_col[GL_B], b_prod[GL_B];
+#pragma unroll
+    for (int i = 0; i < GL_B; ++i) {
+        int rs, c;
+        if (NB == 2) { rs = 2 * (2 * w + i) + (lane >> 5); c = lane & 31; }
+        else { rs = 4 * w + (lane >> 4); c = lane & 15; }
+        const int cs = ((c >> 1) ^ v2_swz(rs)) << 1 | (c & 1);
+        b_row[i] = rs; b_prod[i] = cs >> 4; b_col[i] = (cs & 15) * 8;
+    }
+    auto issue = [&](int k) {                            // stage k -> ring slot k % NBUF (always issued: the counts stay static)
+        char* buf = smem + (k % NBUF) * ST_BYTES;
+        const int r0 = k < nst ? r_begin + k * V2_KC : r_end;      // over-issued tail stages read the zero line
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            const bf16_t* A = reinterpret_cast<const bf16_t*>(pl ? a.A_lo : a.A);
+#pragma unroll
+            for (int i = 0; i < GL_A; ++i) {
+                const int r = r0 + a_row[i];
+                const bf16_t* src = r < r_end ? A + (size_t)r * a.lda + m0 + a_col[i] : zeros;
+                __builtin_amdgcn_global_load_lds((gbl_cvoid*)src, (lds_void*)(buf + pl * OFF_ALO + (2 * w + i) * 1024), 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < GL_B; ++i) {
+                const int r = r0 + b_row[i];
+                const bool second = NB == 2 ? b_prod[i] == 1 : false;
+                const bf16_t* base = reinterpret_cast<const bf16_t*>(second ? (pl ? a.Bm2_lo : a.Bm2) : (pl ? a.Bm_lo : a.Bm));
+                const int sh = second ? a.shift_T2 : a.shift_T;
+                bool ok = r < r_end;
+                int rr = ok ? r : r_begin;
+                if (sh > 0) { ok = ok && ((rr / a.shift_rows) % sh != 0); rr -= a.shift_rows; }
+                else if (!second && a.bcast_T > 0) rr = (rr / (a.shift_rows * a.bcast_T)) * a.shift_rows + rr % a.shift_rows;
+                const bf16_t* src = ok ? base + (size_t)rr * a.ldb + b_col[i] : zeros;
+                __builtin_amdgcn_global_load_lds((gbl_cvoid*)src, (lds_void*)(buf + (pl ? OFF_BLO : OFF_BHI) + ((NB == 2 ? 2 * w : 0) + (NB == 2 ? i : w)) * 1024), 16, 0, 0);
+            }
+            if constexpr (XP) {
+                if (w == 0) {
+                    const int r = r0 + (lane >> 1);
+                    const bf16_t* src = r < r_end ? reinterpret_cast<const bf16_t*>(pl ? a.Bx_lo : a.Bx) + (size_t)r * 16 + (lane & 1) * 8 : zeros;
+                    __builtin_amdgcn_global_load_lds((gbl_cvoid*)src, (lds_void*)(buf + (pl ? OFF_XLO : OFF_XHI)), 16, 0, 0);
+                }
+            }
+        }
+    };
+
+    f32x4 acc[8][NJ], accx[XP ? 8 : 1];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int jn = 0; jn < NJ; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < (XP ? 8 : 1); ++i) accx[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int tr_r = 8 * g + qq, fz = v2_swz(tr_r);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
+    uint32_t a_off[8], b_off[NJ];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a_off[i] = tr_r * (V2_MT * 2) + (((wm * 8 + i) ^ fz) << 5) + pp * 8;
+#pragma unroll
+    for (int jn = 0; jn < NJ; ++jn) b_off[jn] = tr_r * (NT * 2) + (((wn * NJ + jn) ^ fz) << 5) + pp * 8;
+    auto frag = [](s16x4 lo, s16x4 hi) { return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)); };
+    auto compute = [&](int k) {
+        const uint32_t buf = lds0 + (k % NBUF) * ST_BYTES;
+        s16x4 alo[8], ahi[8], blo[NJ], bhi[NJ], clo[NJ], chi[NJ], xlo = {0, 0, 0, 0}, xhi = {0, 0, 0, 0}, ylo = {0, 0, 0, 0}, yhi = {0, 0, 0, 0};
+        // A_hi, B_hi, B_lo (, X_hi, X_lo) fragments; inline asm for the reason given in v2
+        if constexpr (XP) {
+            asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:128" : "=&v"(xlo), "=&v"(xhi) : "v"(buf + OFF_XHI + tr_r * 32 + pp * 8));
+            asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:128" : "=&v"(ylo), "=&v"(yhi) : "v"(buf + OFF_XLO + tr_r * 32 + pp * 8));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3" : "=&v"(alo[i]), "=&v"(ahi[i]) : "v"(buf + a_off[i]), "n"(4 * V2_MT * 2));
+#pragma unroll
+        for (int jn = 0; jn < NJ; ++jn) {
+            asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3" : "=&v"(blo[jn]), "=&v"(bhi[jn]) : "v"(buf + OFF_BHI + b_off[jn]), "n"(4 * NT * 2));
+            asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3" : "=&v"(clo[jn]), "=&v"(chi[jn]) : "v"(buf + OFF_BLO + b_off[jn]), "n"(4 * NT * 2));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(alo[0]), "+v"(ahi[0]), "+v"(alo[1]), "+v"(ahi[1]), "+v"(alo[2]), "+v"(ahi[2]), "+v"(alo[3]), "+v"(ahi[3]),
+                       "+v"(alo[4]), "+v"(ahi[4]), "+v"(alo[5]), "+v"(ahi[5]), "+v"(alo[6]), "+v"(ahi[6]), "+v"(alo[7]), "+v"(ahi[7]),
+                       "+v"(xlo), "+v"(xhi), "+v"(ylo), "+v"(yhi));
+#pragma unroll
+        for (int jn = 0; jn < NJ; ++jn) asm volatile("" : "+v"(blo[jn]), "+v"(bhi[jn]), "+v"(clo[jn]), "+v"(chi[jn]));
+        bf16x8 bh[NJ], bl[NJ];
+#pragma unroll
+        for (int jn = 0; jn < NJ; ++jn) { bh[jn] = frag(blo[jn], bhi[jn]); bl[jn] = frag(clo[jn], chi[jn]); }
+        // A_lo fragments are requested now and waited for behind the two A_hi products
+        s16x4 dlo[8], dhi[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3" : "=&v"(dlo[i]), "=&v"(dhi[i]) : "v"(buf + OFF_ALO + a_off[i]), "n"(4 * V2_MT * 2));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bf16x8 af = frag(alo[i], ahi[i]);
+#pragma unroll
+            for (int jn = 0; jn < NJ; ++jn) acc[i][jn] = mfma_bf16_16x16x32(af, bh[jn], acc[i][jn]);
+#pragma unroll
+            for (int jn = 0; jn < NJ; ++jn) acc[i][jn] = mfma_bf16_16x16x32(af, bl[jn], acc[i][jn]);
+            if constexpr (XP) {
+                if (wn == 0) { accx[i] = mfma_bf16_16x16x32(af, frag(xlo, xhi), accx[i]); accx[i] = mfma_bf16_16x16x32(af, frag(ylo, yhi), accx[i]); }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(dlo[0]), "+v"(dhi[0]), "+v"(dlo[1]), "+v"(dhi[1]), "+v"(dlo[2]), "+v"(dhi[2]), "+v"(dlo[3]), "+v"(dhi[3]),
+                       "+v"(dlo[4]), "+v"(dhi[4]), "+v"(dlo[5]), "+v"(dhi[5]), "+v"(dlo[6]), "+v"(dhi[6]), "+v"(dlo[7]), "+v"(dhi[7]));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bf16x8 af = frag(dlo[i], dhi[i]);
+#pragma unroll
+            for (int jn = 0; jn < NJ; ++jn) acc[i][jn] = mfma_bf16_16x16x32(af, bh[jn], acc[i][jn]);
+            if constexpr (XP) {
+                if (wn == 0) accx[i] = mfma_bf16_16x16x32(af, frag(xlo, xhi), accx[i]);
+            }
+        }
+    };
+
+#pragma unroll
+    for (int k = 0; k < NBUF - 1; ++k) issue(k);
+    for (int k = 0; k < nst; ++k) {
+        // stage k has landed; NBUF - 2 younger stages stay in flight
+        if constexpr (NBUF == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (XP && w == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * (PS + 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * PS) : "memory");
+        __builtin_amdgcn_s_barrier();                     // everyone's part of stage k is in LDS, everyone is done with the slot stage k + NBUF - 1 goes to
+        issue(k + NBUF - 1);
+        compute(k);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS-DMA may outlive the workgroup
+
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int jn = 0; jn < NJ; ++jn) {
+            const int ncol = (wn * NJ + jn) * 16 + i16, kb = ncol >> 7, n = ncol & 127;
+            float* C = kb == 0 ? a.C : a.C2;
+            float* dst = nsplit == 1 ? C : a.partial + ((size_t)split * NB + kb) * a.M * a.N;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 128 + i * 16 + g * 4 + r;
+                dst[(size_t)m * a.N + n] = acc[i][jn][r];
+            }
+        }
+    if constexpr (XP) {
+        if (wn == 0 && i16 < a.Nx) {
+            float* dst = nsplit == 1 ? a.Cx : a.partial + (size_t)nsplit * NB * a.M * a.N + (size_t)split * a.M * a.Nx;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[(size_t)(m0 + wm * 128 + i * 16 + g * 4 + r) * a.Nx + i16] = accx[i][r];
+        }
+    }
+}
+
 struct Geo { int tiles_m, tiles_n, nsplit, rows_per_split; };
 bool v2_ok(const GemmTnArgsB& a) {
     if (a.bcast_T > 0 && !(a.M % V2_MT == 0 && a.N == 128)) return false;
@@ -402,7 +592,21 @@ int launch_gemm_tn_bf16(const GemmTnArgsB& a, hipStream_t s, ReduceJobs* defer) 
     SHM_REQUIRE(!a.Bx || (xp && a.Cx && a.Nx >= 1 && a.Nx <= 16), SHM_EINVAL, "gemm_tn_bf16: the 16-column product needs the H = 128 kernel with NB == 1");
     SHM_REQUIRE(g.nsplit == 1 || (a.partial && a.partial_elems >= (size_t)g.nsplit * (a.NB * a.M * a.N + (xp ? a.M * a.Nx : 0))), SHM_EWORKSPACE,
                 "gemm_tn_bf16: split-K scratch too small");
-    if (v2) {
+    static const bool sp_v2 = [] { const char* e = getenv("SHM_GEMM_SP_V2"); return e && e[0] == '1'; }();     // A/B knob: the round-2 three-pass form
+    if (v2 && a.nseg > 1 && !sp_v2) {
+        const int grid = round_up(g.nsplit, 8) * g.tiles_m;
+        const size_t st = 2 * ((size_t)V2_KC * V2_MT * 2 + (size_t)V2_KC * 128 * a.NB * 2 + (xp ? V2_KC * 16 * 2 : 0));
+        const size_t lds = (a.NB == 2 ? 2 : 3) * st;
+        void (*kern)(GemmTnArgsB, int, int, int) = a.NB == 2 ? gemm_tn_sp_v3_kernel<2, false> : (xp ? gemm_tn_sp_v3_kernel<1, true> : gemm_tn_sp_v3_kernel<1, false>);
+        static const void* raised[3] = {nullptr, nullptr, nullptr};
+        bool done = false;
+        for (const void* k : raised) done = done || k == (const void*)kern;
+        if (!done) {
+            SHM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            for (auto& k : raised) if (!k) { k = (const void*)kern; break; }
+        }
+        SHM_LAUNCH(kern, dim3(grid), dim3(512), lds, s, a, g.tiles_m, g.rows_per_split, g.nsplit);
+    } else if (v2) {
         const int grid = round_up(g.nsplit, 8) * g.tiles_m;
         const size_t lds = (size_t)V2_NBUF * (V2_KC * V2_MT * 2 + V2_KC * 128 * a.NB * 2 + (xp ? V2_KC * 16 * 2 : 0));
         if (a.NB == 2) {
