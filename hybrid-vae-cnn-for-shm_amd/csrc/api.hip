@@ -1084,7 +1084,28 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
                 a.WhT_hi = at<bf16_t>(ws, st[l].WhT); a.WhT_lo = at<bf16_t>(ws, st[l].WhT_lo);
                 a.dpre_hi = dph; a.dpre_lo = dpl; a.dpre_tsum = tsum; a.B = B; a.T = T;
                 int r;
-                {
+                DxArgsS da;
+                memset(&da, 0, sizeof(da));
+                if (l > 0) {
+                    da.dpre_hi = dph; da.dpre_lo = dpl; da.WxT_hi = at<bf16_t>(ws, st[l].WxT); da.WxT_lo = at<bf16_t>(ws, st[l].WxT_lo);
+                    da.dx = dx_seq; da.rows = Rt; da.drop_p = drop; da.drop_seed = p->drop_seed; da.drop_stack = stack;
+                }
+                // (r3) the top layer's recurrence and dx of the layer below in ONE launch (the dx workgroup of a tile follows the recurrence of
+                // that tile): same-box A/B 2.12 -> 2.04 ms per step.  SHM_SP_BWD_DX_PAIR=0 or pair launches off: two launches, same bits.
+                static const bool dx_pair = [] { const char* e = getenv("SHM_SP_BWD_DX_PAIR"); return !(e && e[0] == '0'); }();
+                const bool fuse_dx = dx_pair && l > 0 && l == L - 1 && T % 4 == 0 && p->pair_sync && pair_launch_enabled();
+                if (fuse_dx) {
+                    LstmBwdDxPairArgsS pa;
+                    memset(&pa, 0, sizeof(pa));
+                    pa.top = a; pa.dx = da;
+                    pa.sync = at<unsigned>(ws, p->pair_sync + (size_t)p->sync_next * lstm_fwd_pair_sync_bytes(B));
+                    pa.sync_other = at<unsigned>(ws, p->pair_sync + (size_t)(p->sync_next ^ 1) * lstm_fwd_pair_sync_bytes(B));
+                    p->sync_next ^= 1;
+                    pa.err = at<unsigned>(ws, p->misc);
+                    snprintf(nm, sizeof(nm), "lstm_bwd.%s%d", sn, l);
+                    KernelTimer kt(nm, s);
+                    r = launch_lstm_bwd_dx_pair_sp(H, pa, s);
+                } else {
                     snprintf(nm, sizeof(nm), "lstm_bwd.%s%d", sn, l);
                     KernelTimer kt(nm, s);
                     r = launch_lstm_bwd_sp(H, a, s);
@@ -1093,11 +1114,7 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
                 // the recurrence is enqueued: NOW hand the previous layers' weight-gradient products to the side stream (a recurrent
                 // launch holds 128 CUs; enqueued first it gets them, and the GEMMs fill what is left instead of the other way round)
                 if ((r = flush_deferred())) return r;
-                if (l > 0) {              // gradient on the layer below's h_t, all steps at once
-                    DxArgsS da;
-                    memset(&da, 0, sizeof(da));
-                    da.dpre_hi = dph; da.dpre_lo = dpl; da.WxT_hi = at<bf16_t>(ws, st[l].WxT); da.WxT_lo = at<bf16_t>(ws, st[l].WxT_lo);
-                    da.dx = dx_seq; da.rows = Rt; da.drop_p = drop; da.drop_seed = p->drop_seed; da.drop_stack = stack;
+                if (l > 0 && !fuse_dx) {  // gradient on the layer below's h_t, all steps at once
                     snprintf(nm, sizeof(nm), "dx_gemm.%s%d", sn, l);
                     KernelTimer kt(nm, s);
                     if ((r = launch_dx_sp(H, da, s))) return r;

@@ -272,6 +272,11 @@ struct DxArgsS {
     int cpt, seq_tiles, tile_off, n_chunk_tiles;  // time chunk, as in XprojArgsS
 };
 int launch_dx_sp(int H, const DxArgsS& a, hipStream_t s);
+// (r3) the top layer's backward recurrence and dx = dpre W_ih of the layer below in ONE launch: the dx workgroup of a tile follows the
+// recurrence of that tile inside the launch (sc1 hand-off of the dpre planes).  top: the top layer's arguments (whole window, no dh_seq);
+// dx: the arguments launch_dx_sp would get (rows / chunk fields unused).  T % 4 == 0.  Bit-identical to the two launches.
+struct LstmBwdDxPairArgsS { LstmBwdArgsS top; DxArgsS dx; unsigned* sync; unsigned* sync_other; unsigned* err; int role_lds_off; };
+int launch_lstm_bwd_dx_pair_sp(int H, const LstmBwdDxPairArgsS& p, hipStream_t s);
 // fp32 [n_valid] -> bf16 planes hi, lo of n >= n_valid elements (the tail is zero-filled: padding windows of the last tile)
 int launch_split_planes(const float* src, size_t n_valid, size_t n, bf16_t* hi, bf16_t* lo, hipStream_t s);
 

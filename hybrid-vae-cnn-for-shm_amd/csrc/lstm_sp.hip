@@ -676,8 +676,12 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_pair_sp_kernel(LstmFwdPairArgs
 // 2 output layer with exactly 4 channels (raw dy prefetched, product with W_out at use), 3 any other channel count.
 struct PrefS { f32x4 r4; f32x2 r2; f32x4 up; };
 
-template <int H, int DH>
-__global__ void __launch_bounds__(4 * H) lstm_bwd_sp_kernel(LstmBwdArgsS a) {
+// PRODUCE (lstm_bwd_dx_pair_sp_kernel): the dpre planes are consumed by the dx workgroup of the same tile inside this launch.  All
+// eight waves store a step's planes (one 16-byte chunk per thread) write-through (sc1); each retires its store of DLY steps ago with a
+// counted s_waitcnt right after storing, and lane 0 publishes "steps >= t + DLY are in memory" behind the NEXT step's workgroup barrier
+// (every storing wave has passed its wait by then: the R1 form of cdna_hip_programming.md section 6 G16, as in lstm_bwd_bf16.hip).
+template <int H, int DH, bool PRODUCE>
+__device__ __forceinline__ void lstm_bwd_sp_body(const LstmBwdArgsS& a, const int tile, gu32* flag_out) {
     constexpr int NW = H / 16, NTHR = 64 * NW;
     constexpr int KS = H / 8;                      // k-steps of 32 over K = 4H
     constexpr int RS = lds_row_stride(H);          // quarter q <-> gate q, KQ = H
@@ -686,7 +690,7 @@ __global__ void __launch_bounds__(4 * H) lstm_bwd_sp_kernel(LstmBwdArgsS a) {
     bf16_t* dp_lds = smem_b;                                               // [2][PBUF]  rows 0..3 hi, 4..7 lo of each gate quarter
     float* wo_lds = reinterpret_cast<float*>(smem_b + 2 * PBUF);           // [Dy][H]
 
-    const int T = a.T, B = a.B, Dy = a.Dy, tile = blockIdx.x;
+    const int T = a.T, B = a.B, Dy = a.Dy;
     const int t0 = a.t0, t1 = a.t1;                // this launch walks steps t1-1 down to t0 (a time chunk, or the whole window)
     const int tid = threadIdx.x, lane = tid & 63, ht = tid >> 6, q = lane >> 4, j = lane & 15;
     const int cj = j & 3, cr = j >> 2, cu = ht * 16 + q * 4 + cr;
@@ -741,6 +745,9 @@ __global__ void __launch_bounds__(4 * H) lstm_bwd_sp_kernel(LstmBwdArgsS a) {
     const int fjj = fcch / (4 * H / 8), fc8 = (fcch - fjj * (4 * H / 8)) * 8, fg = fc8 / H, fu = fc8 - fg * H;
     const int f_img_off = (fg * 16 + fjj + 4 * fpl) * RS + fu;
     bf16_t* const f_dst = (fpl ? a.dpre_lo : a.dpre_hi) + (size_t)tile * T * WPT * 4 * H + (size_t)fcch * 8;
+    // PRODUCE: vector-memory instructions every wave issues per step: two record loads + its dpre store (a lower bound)
+    constexpr int OPS = 3;
+    const __amdgpu_buffer_rsrc_t out_rsrc = make_rsrc(PRODUCE ? f_dst - (size_t)fcch * 8 : nullptr, PRODUCE ? (uint32_t)T * WPT * 4 * H * 2 : 0);
 
     auto step = [&](PrefS& P, int t) {
         asm volatile("" : "+v"(P.r4), "+v"(P.r2), "+v"(P.up));
@@ -773,7 +780,14 @@ __global__ void __launch_bounds__(4 * H) lstm_bwd_sp_kernel(LstmBwdArgsS a) {
         }
         fetch(P, t - NSB);
         __syncthreads();
-        *reinterpret_cast<bf16x8*>(f_dst + (size_t)t * WPT * 4 * H) = *reinterpret_cast<const bf16x8*>(dpl + f_img_off);
+        if constexpr (PRODUCE) {
+            // every storing wave has, in step t + 1, waited until its dpre store of step t + DLY had retired
+            if (tid == 0 && t + DLY <= T - 1) __hip_atomic_store(flag_out, (unsigned)(T - (t + DLY)), SHM_RLX_AGENT);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(dpl + f_img_off);
+            __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, (uint32_t)(t * WPT * 4 * H + fcch * 8) * 2, 0, 16);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DLY - 1) * OPS) : "memory");   // retires the store of step t + DLY - 1
+        } else
+            *reinterpret_cast<bf16x8*>(f_dst + (size_t)t * WPT * 4 * H) = *reinterpret_cast<const bf16x8*>(dpl + f_img_off);
         const bf16_t* brow = dpl + (q * 16 + j) * RS;
         f32x4 acc0 = zero4, acc1 = zero4;
 #pragma unroll
@@ -802,6 +816,11 @@ __global__ void __launch_bounds__(4 * H) lstm_bwd_sp_kernel(LstmBwdArgsS a) {
 #pragma unroll
         for (int u = 0; u < NSB; ++u) step(P[u], t - u);
     }
+    if constexpr (PRODUCE) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(flag_out, (unsigned)T, SHM_RLX_AGENT);
+    }
     if (t0 > 0 && bst) bst[0] = f32x2{dc, dh_rec};
     if (cvalid && a.dpre_tsum) {                   // sum_t dpre: the chunk that runs first (t1 == T) writes, later chunks add
 #pragma unroll
@@ -810,6 +829,131 @@ __global__ void __launch_bounds__(4 * H) lstm_bwd_sp_kernel(LstmBwdArgsS a) {
             *d = t1 < T ? *d + tsum[g] : tsum[g];
         }
     }
+}
+
+template <int H, int DH>
+__global__ void __launch_bounds__(4 * H) lstm_bwd_sp_kernel(LstmBwdArgsS a) {
+    lstm_bwd_sp_body<H, DH, false>(a, blockIdx.x, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// (r3) Top-layer backward + dx in one launch.  The top layer's recurrence holds 128 of the 256 CUs, and dx = dpre W_ih of the layer
+// below used to be a full-chip launch BEHIND it (94 us, twice per step, on the step's critical path).  Here the workgroup of tile i in the
+// second half of the grid forms dx for tile i's rows while the recurrence of tile i is still running: it follows the producer's progress
+// word (16 rows = 4 steps at a time, walking down in time as the recurrence does), reads the dpre planes with sc1 loads only, and runs
+// dx_sp_kernel's own loop body on them — same fragments, same three products in the same order, same mask: bit-identical output.
+// W_ih^T hi / lo live in registers (this role has no recurrent weights); the layer-0 recurrence stays its own launch behind this one.
+template <int H, bool DROP>
+__device__ __forceinline__ void dx_sp_follow(const DxArgsS& a, const int tile, const int T, gu32* flag_in, gu32* err) {
+    constexpr int NW = H / 16, NTHR = 64 * NW, KS = H / 8, RS = lds_row_stride(H), PBUF = 4 * 16 * RS;
+    extern __shared__ __attribute__((aligned(16))) bf16_t simg[];         // [buf][plane][PBUF]
+    const int tid = threadIdx.x, lane = tid & 63, ht = tid >> 6, q = lane >> 4, j = lane & 15;
+    bf16x8 whi[KS], wlo[KS];
+    {
+        const size_t off = (size_t)ht * KS * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            whi[s] = reinterpret_cast<const bf16x8*>(a.WxT_hi)[off + s * 64];
+            wlo[s] = reinterpret_cast<const bf16x8*>(a.WxT_lo)[off + s * 64];
+        }
+    }
+    const uint32_t thr = drop_threshold(a.drop_p);
+    const float dscale = DROP ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    const uint32_t seq_bytes = (uint32_t)T * WPT * 4 * H * 2;
+    const __amdgpu_buffer_rsrc_t in_hi = make_rsrc(a.dpre_hi + (size_t)tile * T * WPT * 4 * H, seq_bytes);
+    const __amdgpu_buffer_rsrc_t in_lo = make_rsrc(a.dpre_lo + (size_t)tile * T * WPT * 4 * H, seq_bytes);
+    int avail = 0;                                         // wave-uniform: the producer's steps >= T - avail are in memory
+    auto wait_for = [&](int need) {
+        if (avail >= need) return;
+        unsigned v, spins = 0;
+#pragma clang loop unroll(disable)
+        for (;;) {
+            v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flag_in, SHM_RLX_AGENT));
+            if ((int)v >= need) break;
+            if (++spins > SPIN_MAX) {
+                if (lane == 0) __hip_atomic_store(err, 0x40000001u + (unsigned)tile, SHM_RLX_AGENT);
+                v = 0x7fffffff;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        avail = (int)v;
+    };
+    constexpr int CHP = 16 * 4 * H / 8, CPT = 2 * CHP / NTHR;            // chunks per plane; = 4 chunks per thread
+    static_assert(CPT * NTHR == 2 * CHP && CHP % NTHR == 0, "whole chunks per thread, a thread's chunks stay in one plane");
+    const int n_loc = (T * WPT + 15) / 16;                               // 16-row tiles of this window tile (the last one may be partial)
+    u32x4 st[CPT];
+    auto load_tile = [&](int c) {                                         // rows 16c .. 16c+15 of the tile = steps 4c .. 4c+3
+        wait_for(T - 4 * c);
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int e = tid + i * NTHR, pl = e >= CHP ? 1 : 0, cch = e - pl * CHP;      // pl is wave-uniform (CHP % NTHR == 0)
+            const uint32_t off = (uint32_t)(c * 16 * 4 * H + cch * 8) * 2;                // rows past the window: out of range, read as zero
+            st[i] = pl ? __builtin_amdgcn_raw_buffer_load_b128(in_lo, off, 0, 16) : __builtin_amdgcn_raw_buffer_load_b128(in_hi, off, 0, 16);
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int e = tid + i * NTHR, pl = e >= CHP ? 1 : 0, cch = e - pl * CHP;
+            const int jj = cch / (4 * H / 8), c8 = (cch - jj * (4 * H / 8)) * 8, g = c8 / H, u = c8 - g * H;
+            *reinterpret_cast<u32x4*>(simg + (buf * 2 + pl) * PBUF + (g * 16 + jj) * RS + u) = st[i];
+        }
+    };
+    int c = n_loc - 1;
+    load_tile(c); store_tile(0);
+    __syncthreads();
+    for (int it = 0; c >= 0; --c, ++it) {
+        const int cur = it & 1;
+        if (c > 0) load_tile(c - 1);
+        const bf16_t* bh = simg + cur * 2 * PBUF + (q * 16 + j) * RS;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; s += 2) {
+            const bf16x8 h0 = *reinterpret_cast<const bf16x8*>(bh + 8 * s), h1 = *reinterpret_cast<const bf16x8*>(bh + 8 * s + 8);
+            const bf16x8 l0 = *reinterpret_cast<const bf16x8*>(bh + PBUF + 8 * s), l1 = *reinterpret_cast<const bf16x8*>(bh + PBUF + 8 * s + 8);
+            acc0 = mfma_bf16_16x16x32(whi[s], h0, acc0);
+            acc1 = mfma_bf16_16x16x32(whi[s + 1], h1, acc1);
+            acc0 = mfma_bf16_16x16x32(wlo[s], h0, acc0);
+            acc1 = mfma_bf16_16x16x32(wlo[s + 1], h1, acc1);
+            acc0 = mfma_bf16_16x16x32(whi[s], l0, acc0);
+            acc1 = mfma_bf16_16x16x32(whi[s + 1], l1, acc1);
+        }
+        f32x4 d = acc0 + acc1;
+        // global 16-row tile index: dx_sp_kernel numbers the tiles over ALL rows; a window tile starts on a 16-row boundary iff T % 4 == 0
+        // (the launcher requires it for this kernel)
+        const size_t gt = (size_t)tile * (T * WPT / 16) + c;
+        if (DROP) {
+            const uint32_t base = (uint32_t)((gt * 16 + j) * H + ht * 16 + q * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = drop_hash(a.drop_seed, a.drop_stack, base + e) >= thr ? d[e] * dscale : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(a.dx + ((gt * NW + ht) * 64 + lane) * 4) = d;
+        if (c > 0) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+}
+
+template <int H, int DH, bool DROP>
+__global__ void __launch_bounds__(4 * H) lstm_bwd_dx_pair_sp_kernel(LstmBwdDxPairArgsS p) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem_b[];
+    gu32* sync = (gu32*)p.sync;
+    const int tiles = gridDim.x >> 1;
+    int* role_lds = reinterpret_cast<int*>(reinterpret_cast<char*>(smem_b) + p.role_lds_off);
+    if (threadIdx.x == 0) *role_lds = (int)__hip_atomic_fetch_add(sync, 1u, SHM_RLX_AGENT);
+    __syncthreads();
+    const int ticket = *role_lds;
+    __syncthreads();
+    const int grp = ticket / (2 * PAIR_GROUP), r = ticket - grp * 2 * PAIR_GROUP, base = grp * PAIR_GROUP;
+    const int ntg = min(PAIR_GROUP, tiles - base);
+    const bool producer = r < ntg;
+    const int tile = base + (producer ? r : r - ntg);
+    if (threadIdx.x == 0 && producer) {
+        p.sync_other[16 * (1 + tile)] = 0u;
+        if (ticket == 0) p.sync_other[0] = 0u;
+    }
+    if (producer) lstm_bwd_sp_body<H, DH, true>(p.top, tile, sync + 16 * (1 + tile));
+    else dx_sp_follow<H, DROP>(p.dx, tile, p.top.T, sync + 16 * (1 + tile), (gu32*)p.err);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1047,6 +1191,32 @@ int launch_fwd_pair_h(const LstmFwdPairArgsS& p0, hipStream_t s) {
     return SHM_OK;
 }
 
+template <int H>
+int launch_bwd_dx_pair_h(const LstmBwdDxPairArgsS& p0, hipStream_t s) {
+    LstmBwdDxPairArgsS p = p0;
+    const LstmBwdArgsS& a = p.top;
+    const int tiles = ceil_div(a.B, WPT);
+    const size_t lds_top = sizeof(bf16_t) * 2 * 4 * 16 * lds_row_stride(H) + sizeof(float) * (a.dy ? a.Dy * H : 0);
+    const size_t lds_dx = sizeof(bf16_t) * 2 * 2 * 4 * 16 * lds_row_stride(H);
+    const size_t lds = lds_top > lds_dx ? lds_top : lds_dx;
+    p.role_lds_off = (int)lds;
+    const bool drop = p.dx.drop_p > 0.f;
+    void (*kern)(LstmBwdDxPairArgsS);
+    if (a.dy) kern = a.Dy == 4 ? (drop ? lstm_bwd_dx_pair_sp_kernel<H, 2, true> : lstm_bwd_dx_pair_sp_kernel<H, 2, false>)
+                               : (drop ? lstm_bwd_dx_pair_sp_kernel<H, 3, true> : lstm_bwd_dx_pair_sp_kernel<H, 3, false>);
+    else kern = drop ? lstm_bwd_dx_pair_sp_kernel<H, 0, true> : lstm_bwd_dx_pair_sp_kernel<H, 0, false>;
+    static const void* raised[8] = {nullptr};
+    bool done = false;
+    for (const void* k : raised) done = done || k == (const void*)kern;
+    if (!done) {
+        SHM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + 16)));
+        for (auto& k : raised) if (!k) { k = (const void*)kern; break; }
+    }
+    SHM_LAUNCH(kern, dim3(2 * tiles), dim3(4 * H), lds + 16, s, p);
+    SHM_LAUNCH_CHECK();
+    return SHM_OK;
+}
+
 inline int tiles_per_wg_for(int n_tiles) { return n_tiles >= 2048 ? 8 : 1; }
 
 template <int H>
@@ -1126,6 +1296,25 @@ int launch_lstm_bwd_sp(int H, const LstmBwdArgsS& a0, hipStream_t s) {
     SHM_REQUIRE(a.rec4 && a.rec2 && a.dpre_hi && a.dpre_lo && a.WhT_hi && a.WhT_lo, SHM_ESTATE, "lstm_bwd_sp: no saved forward state / dpre planes / weights");
     SHM_REQUIRE(!a.dy || (a.Wout && a.Dy > 0 && a.Dy <= 64), SHM_EINVAL, "lstm_bwd_sp: bad output-layer gradient");
     SHM_DISPATCH_H(launch_bwd_h, "lstm_bwd_sp")
+}
+int launch_lstm_bwd_dx_pair_sp(int H, const LstmBwdDxPairArgsS& a0, hipStream_t s) {
+    LstmBwdDxPairArgsS a = a0;
+    LstmBwdArgsS& t = a.top;
+    if (t.t1 == 0) { t.t0 = 0; t.t1 = t.T; }
+    SHM_REQUIRE(t.B > 0 && t.T > 0 && t.t0 == 0 && t.t1 == t.T, SHM_EINVAL, "lstm_bwd_dx_pair_sp: whole windows only");
+    SHM_REQUIRE(t.T % 4 == 0, SHM_EINVAL, "lstm_bwd_dx_pair_sp: T must be a multiple of 4 (a window tile = whole 16-row dx tiles)");
+    SHM_REQUIRE(t.rec4 && t.rec2 && t.dpre_hi && t.dpre_lo && t.WhT_hi && t.WhT_lo, SHM_ESTATE, "lstm_bwd_dx_pair_sp: no saved forward state / dpre planes / weights");
+    SHM_REQUIRE(!t.dh_seq, SHM_EINVAL, "lstm_bwd_dx_pair_sp: the producer is the TOP layer of a stack (no dx input of its own)");
+    SHM_REQUIRE(!t.dy || (t.Wout && t.Dy > 0 && t.Dy <= 64), SHM_EINVAL, "lstm_bwd_dx_pair_sp: bad output-layer gradient");
+    SHM_REQUIRE(a.dx.dpre_hi == t.dpre_hi && a.dx.dpre_lo == t.dpre_lo && a.dx.WxT_hi && a.dx.WxT_lo && a.dx.dx, SHM_EINVAL, "lstm_bwd_dx_pair_sp: the dx role must read the top layer's dpre planes");
+    SHM_REQUIRE(a.sync && a.sync_other && a.sync != a.sync_other && a.err, SHM_EINVAL, "lstm_bwd_dx_pair_sp: sync blocks or status word missing");
+    SHM_REQUIRE((int64_t)t.T * WPT * 4 * H * 2 < ((int64_t)1 << 31), SHM_EINVAL, "lstm_bwd_dx_pair_sp: T too long for 32-bit buffer offsets");
+    switch (H) {
+        case 32: return launch_bwd_dx_pair_h<32>(a, s);
+        case 64: return launch_bwd_dx_pair_h<64>(a, s);
+        case 128: return launch_bwd_dx_pair_h<128>(a, s);
+        default: set_error("lstm_bwd_dx_pair_sp: hidden_dim %d unsupported (32, 64, 128)", H); return SHM_EINVAL;
+    }
 }
 int launch_xproj_sp(int H, const XprojArgsS& a, hipStream_t s) {
     SHM_REQUIRE(a.rows > 0 && a.in_hi && a.in_lo && a.W_hi && a.W_lo && a.bias && a.out, SHM_EINVAL, "xproj_sp: operand missing");
