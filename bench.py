@@ -85,7 +85,7 @@ PMC_KERNELS = {
                            "enc0": "lstm_fwd_sp_kernel<128, 2, true>", "enc1": "lstm_fwd_sp_kernel<128, 0, true>",
                            "dec0": "lstm_fwd_sp_kernel<128, 1, true>", "dec1": "lstm_fwd_sp_kernel<128, 0, true>"},
               "lstm_bwd": {"enc0": "lstm_bwd_sp_kernel<128, 1>", "dec0": "lstm_bwd_sp_kernel<128, 1>",
-                           "enc1": "lstm_bwd_sp_kernel<128, 0>", "dec1": "lstm_bwd_sp_kernel<128, 2>"}},
+                           "enc1": "lstm_bwd_dx_pair_sp_kernel<128, 0", "dec1": "lstm_bwd_dx_pair_sp_kernel<128, 2"}},
 }
 
 
@@ -357,6 +357,8 @@ def measure(precision, data, dev, world, rank, steps, warmup, profile_steps, dis
         cand = [k for k in per if kernel_alg_flops(k, B_PER_GPU, precision) > 0 and not (precision == "split" and k.startswith("dw_gemm."))]
         dom = max(cand, key=lambda k: per[k])
         fl = kernel_alg_flops(dom, B_PER_GPU, precision)
+        if precision == "split" and dom in ("lstm_bwd.enc1", "lstm_bwd.dec1") and f"dx_gemm.{dom[-4:]}" not in per:
+            fl += kernel_alg_flops(f"dx_gemm.{dom[-4:]}", B_PER_GPU, precision)     # the top layer's launch also forms dx of the layer below
         achieved = fl / (per[dom] * 1e-3) / 1e12
         peak = PEAK_TFLOPS[dt_key]
         traffic, why = pmc_traffic_checked(dom, precision)

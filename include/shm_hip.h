@@ -33,7 +33,10 @@ extern "C" {
 #define SHM_ESTATE       -3   /* call order violated (e.g. backward without a training forward) */
 
 /* SHM_PREC_SPLIT: every MFMA operand is a pair of bf16 values hi + lo (16 significant bits), products hi*hi + hi*lo + lo*hi in fp32:
- * holds the reference's fp32 results to ~1e-6 (the 1e-4 parity bar) at bf16 matrix rates — the fast parity path. */
+ * holds the reference's fp32 results to ~1e-6 (the 1e-4 parity bar) at bf16 matrix rates — the fast parity path.  Since round 3 the
+ * forward input projections W_ih x of layers whose input is a hidden vector use W_ih ~ fp16(W) + e4m3((W - fp16 W) 2^15) 2^-15 (15
+ * significant bits, measured at the same 5e-6 level) with x as an fp16 pair + e4m3: that W_ih fits a CU beside W_hh, which lets both
+ * layers of a stack run as one layer-pipelined launch. */
 enum { SHM_PREC_F32 = 0, SHM_PREC_BF16 = 1, SHM_PREC_SPLIT = 2 };
 
 /* Constructor arguments of TemporalVAE (4DOF/Scripts/Models/temporal_vae.py:14-21; the 1_DOF variant
@@ -109,8 +112,9 @@ int  shm_vae_decode(shm_vae_plan* plan, const float* z, float* recon,
 int  shm_window_gather(const float* series, int64_t n_rows, int32_t D, const int32_t* starts, int32_t N, int32_t T,
                        const float* mean, const float* std, float clip_z, float* out, void* stream);
 
-/* Health of the layer-pipelined launches (bf16 path, 2 layers: both LSTM layers of a stack run in ONE launch, the upper
- * layer consuming the lower layer's h_t a few steps behind through in-launch flags).  Synchronises the stream.  SHM_OK, or
+/* Health of the layer-pipelined launches (bf16 and split paths, 2 layers: both LSTM layers of a stack run in ONE launch, the upper
+ * layer consuming the lower layer's h_t a few steps behind through in-launch flags; split path also: dx of the layer below formed
+ * behind the top layer's backward recurrence inside its launch).  Synchronises the stream.  SHM_OK, or
  * SHM_ESTATE if a consumer workgroup ever gave up waiting (the word is sticky: every result since its last reset is then invalid).
  * No reference counterpart: nn.LSTM (temporal_vae.py:32,44) hides its layer loop. */
 int  shm_vae_plan_status(const shm_vae_plan* plan, const void* workspace, void* stream);

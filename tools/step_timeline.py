@@ -9,8 +9,11 @@ import sys
 
 
 def short(n):
-    n = re.sub(r"\(.*", "", n)
-    n = n.replace("void shm::(anonymous namespace)::", "").replace("shm::", "")
+    n = n.replace("void shm::(anonymous namespace)::", "").replace("shm::(anonymous namespace)::", "").replace("shm::", "")
+    n = re.sub(r"\(shm::.*|\(int,.*|\(float.*", "", n)
+    m = re.match(r"_ZN3shm12_GLOBAL__N_1\d+([a-z_0-9]+?)(?:I|E)", n)
+    if m:
+        n = m.group(1)
     return n[:58]
 
 
