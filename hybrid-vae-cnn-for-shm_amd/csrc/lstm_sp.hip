@@ -882,30 +882,30 @@ __device__ __forceinline__ void dx_sp_follow(const DxArgsS& a, const int tile, c
     constexpr int CHP = 16 * 4 * H / 8, CPT = 2 * CHP / NTHR;            // chunks per plane; = 4 chunks per thread
     static_assert(CPT * NTHR == 2 * CHP && CHP % NTHR == 0, "whole chunks per thread, a thread's chunks stay in one plane");
     const int n_loc = (T * WPT + 15) / 16;                               // 16-row tiles of this window tile (the last one may be partial)
-    u32x4 st[CPT];
-    auto load_tile = [&](int c) {                                         // rows 16c .. 16c+15 of the tile = steps 4c .. 4c+3
+    // two register sets: the rows of tile c - 2 are requested before tile c is multiplied (one tile of look-ahead left the role latency-bound:
+    // 4.4 us per tile against the 3.5 us the recurrence takes for four steps, i.e. the launch ended 50-80 us behind its recurrence)
+    struct Stage { u32x4 v[CPT]; };
+    auto load_tile = [&](Stage& S, int c) {                               // rows 16c .. 16c+15 of the tile = steps 4c .. 4c+3
+        if (c < 0) return;
         wait_for(T - 4 * c);
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
             const int e = tid + i * NTHR, pl = e >= CHP ? 1 : 0, cch = e - pl * CHP;      // pl is wave-uniform (CHP % NTHR == 0)
             const uint32_t off = (uint32_t)(c * 16 * 4 * H + cch * 8) * 2;                // rows past the window: out of range, read as zero
-            st[i] = pl ? __builtin_amdgcn_raw_buffer_load_b128(in_lo, off, 0, 16) : __builtin_amdgcn_raw_buffer_load_b128(in_hi, off, 0, 16);
+            S.v[i] = pl ? __builtin_amdgcn_raw_buffer_load_b128(in_lo, off, 0, 16) : __builtin_amdgcn_raw_buffer_load_b128(in_hi, off, 0, 16);
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](Stage& S, int buf) {
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
             const int e = tid + i * NTHR, pl = e >= CHP ? 1 : 0, cch = e - pl * CHP;
             const int jj = cch / (4 * H / 8), c8 = (cch - jj * (4 * H / 8)) * 8, g = c8 / H, u = c8 - g * H;
-            *reinterpret_cast<u32x4*>(simg + (buf * 2 + pl) * PBUF + (g * 16 + jj) * RS + u) = st[i];
+            *reinterpret_cast<u32x4*>(simg + (buf * 2 + pl) * PBUF + (g * 16 + jj) * RS + u) = S.v[i];
         }
     };
-    int c = n_loc - 1;
-    load_tile(c); store_tile(0);
-    __syncthreads();
-    for (int it = 0; c >= 0; --c, ++it) {
-        const int cur = it & 1;
-        if (c > 0) load_tile(c - 1);
+    // tile c is multiplied out of image `cur`; Snext holds tile c - 1 (requested an iteration ago), Sfree is refilled with tile c - 2
+    auto tile_step = [&](int c, int cur, Stage& Sfree, Stage& Snext) {
+        load_tile(Sfree, c - 2);
         const bf16_t* bh = simg + cur * 2 * PBUF + (q * 16 + j) * RS;
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -929,9 +929,19 @@ __device__ __forceinline__ void dx_sp_follow(const DxArgsS& a, const int tile, c
             for (int e = 0; e < 4; ++e) d[e] = drop_hash(a.drop_seed, a.drop_stack, base + e) >= thr ? d[e] * dscale : 0.f;
         }
         *reinterpret_cast<f32x4*>(a.dx + ((gt * NW + ht) * 64 + lane) * 4) = d;
-        if (c > 0) store_tile(cur ^ 1);
+        if (c > 0) store_tile(Snext, cur ^ 1);
         __syncthreads();
+    };
+    Stage S0, S1;
+    int c = n_loc - 1;
+    load_tile(S0, c); load_tile(S1, c - 1);
+    store_tile(S0, 0);
+    __syncthreads();
+    for (; c >= 1; c -= 2) {
+        tile_step(c, 0, S0, S1);
+        tile_step(c - 1, 1, S1, S0);
     }
+    if (c == 0) tile_step(0, 0, S0, S1);
 }
 
 template <int H, int DH, bool DROP>
