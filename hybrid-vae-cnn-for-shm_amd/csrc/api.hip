@@ -425,9 +425,9 @@ extern "C" int shm_vae_pack_weights(shm_vae_plan* p, const float* params, void* 
             for (int st = 0; st < 2; ++st) {
                 const LayerInst& li = st == 0 ? p->enc[l] : p->dec[l];
                 add(params + li.b_ih, params + li.b_hh, at<float>(ws, li.bsum), 2, 0);
-                // split path, layers whose input is a hidden vector (layers >= 1 and the constant-input decoder layer 0): W_ih as fp16 +
+                // split path, layers whose input is a hidden SEQUENCE (layers >= 1): W_ih as fp16 +
                 // fp8 residual (kinds 7 / 8, lstm_sp.hip: x_convert); everything else as bf16 (pairs)
-                const bool w16 = sp && (l > 0 || li.in_const);
+                const bool w16 = sp && l > 0;             // (the constant-input decoder layer 0 keeps the bf16 pair: its projection is its own launch)
                 add(params + li.w_ih, nullptr, at<bf16_t>(ws, li.Wx), w16 ? 7 : 0, li.In);
                 add(params + li.w_hh, nullptr, at<bf16_t>(ws, li.Wh), 0, H);
                 if (sp) {
@@ -571,7 +571,7 @@ static int vae_forward_impl(shm_vae_plan* p, const float* x, const float* eps, c
                 xa.out = at<float>(ws, st[0].xproj);
                 int r = launch_split_planes(in0, (size_t)B * H, (size_t)qt * SHM_WPT * H, at<bf16_t>(ws, p->h0_bf), at<bf16_t>(ws, p->h0_lo), s);
                 if (r) return r;
-                xa.in_hi = at<bf16_t>(ws, p->h0_bf); xa.in_lo = at<bf16_t>(ws, p->h0_lo); xa.rows = qt * SHM_WPT;
+                xa.in_hi = at<bf16_t>(ws, p->h0_bf); xa.in_lo = at<bf16_t>(ws, p->h0_lo); xa.rows = qt * SHM_WPT; xa.pair_bf16 = 1;
                 snprintf(nm, sizeof(nm), "xproj.%s0", sn);
                 KernelTimer kt(nm, s);
                 if ((r = launch_xproj_sp(H, xa, s))) return r;
@@ -616,7 +616,7 @@ static int vae_forward_impl(shm_vae_plan* p, const float* x, const float* eps, c
                 xa.out = at<float>(ws, st[0].xproj);
                 int r = launch_split_planes(in0, (size_t)B * H, (size_t)qt * SHM_WPT * H, at<bf16_t>(ws, p->h0_bf), at<bf16_t>(ws, p->h0_lo), s);
                 if (r) return r;
-                xa.in_hi = at<bf16_t>(ws, p->h0_bf); xa.in_lo = at<bf16_t>(ws, p->h0_lo); xa.rows = qt * SHM_WPT;
+                xa.in_hi = at<bf16_t>(ws, p->h0_bf); xa.in_lo = at<bf16_t>(ws, p->h0_lo); xa.rows = qt * SHM_WPT; xa.pair_bf16 = 1;
                 snprintf(nm, sizeof(nm), "xproj.%s0", sn);
                 KernelTimer kt(nm, s);
                 if ((r = launch_xproj_sp(H, xa, s))) return r;
@@ -677,7 +677,7 @@ static int vae_forward_impl(shm_vae_plan* p, const float* x, const float* eps, c
                 if (li.in_const) {        // decoder layer 0: one projection per window (temporal_vae.py:68 repeats h0 over T)
                     int r = launch_split_planes(in0, (size_t)B * H, (size_t)qt * SHM_WPT * H, at<bf16_t>(ws, p->h0_bf), at<bf16_t>(ws, p->h0_lo), s);
                     if (r) return r;
-                    xa.in_hi = at<bf16_t>(ws, p->h0_bf); xa.in_lo = at<bf16_t>(ws, p->h0_lo); xa.rows = qt * SHM_WPT;
+                    xa.in_hi = at<bf16_t>(ws, p->h0_bf); xa.in_lo = at<bf16_t>(ws, p->h0_lo); xa.rows = qt * SHM_WPT; xa.pair_bf16 = 1;
                     a.mode = 1;
                 } else {
                     xa.in_hi = at<bf16_t>(ws, st[l - 1].h_seq); xa.in_lo = at<bf16_t>(ws, st[l - 1].h_lo); xa.rows = qt * SHM_WPT * T;

@@ -261,6 +261,8 @@ struct XprojArgsS {
     // time chunk of every window tile (cpt > 0): the launch covers n_chunk_tiles = tiles * cpt 16-row tiles; chunk-local tile k is the
     // global tile (k / cpt) * seq_tiles + tile_off + k % cpt (seq_tiles = T / 4 tiles per window tile, tile_off = t0 / 4, cpt = (t1 - t0) / 4)
     int cpt, seq_tiles, tile_off, n_chunk_tiles;
+    int pair_bf16;                                // 1: W_hi / W_lo are a bf16 pair (pack kinds 0 / 5), 16-bit arithmetic (constant-input decoder layer 0);
+                                                  // 0: W_hi fp16 + W_lo e4m3 residual (kinds 7 / 8), the arithmetic the fused layer-1 kernel shares
 };
 int launch_xproj_sp(int H, const XprojArgsS& a, hipStream_t s);
 struct DxArgsS {

@@ -1069,6 +1069,64 @@ __global__ void __launch_bounds__(4 * H) xproj_sp_kernel(XprojArgsS a, int tiles
     }
 }
 
+// The same projection on bf16 PAIRS (W_ih hi / lo as pack kinds 0 / 5, three products hi*hi, lo*hi, hi*lo: round 2's arithmetic, 16
+// significant bits) for the one layer whose projection is NOT fused into a recurrent workgroup: the constant-input decoder layer 0
+// (rows = windows, one projection per window, no dropout).  Its own small launch, so residency is not a constraint and the 15-bit W_ih
+// would only cost accuracy — and this projection enters EVERY step of that layer with the same error (emulated: recon 9.4e-7 -> 5.7e-7).
+template <int H>
+__global__ void __launch_bounds__(4 * H) xproj_pair_sp_kernel(XprojArgsS a) {
+    constexpr int NW = H / 16, NTHR = 64 * NW, KS = H / 32, KQ = H / 4, RS = lds_row_stride(KQ), IMG = 4 * 16 * RS;
+    __shared__ __attribute__((aligned(16))) bf16_t img[2 * IMG];          // [plane][IMG]
+    const int tid = threadIdx.x, lane = tid & 63, ht = tid >> 6, q = lane >> 4, j = lane & 15;
+    bf16x8 whi[4][KS], wlo[4][KS];
+    {
+        const size_t off = (size_t)ht * KS * 4 * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                whi[g][s] = reinterpret_cast<const bf16x8*>(a.W_hi)[off + (s * 4 + g) * 64];
+                wlo[g][s] = reinterpret_cast<const bf16x8*>(a.W_lo)[off + (s * 4 + g) * 64];
+            }
+    }
+    f32x4 bias4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias4[g] = *reinterpret_cast<const f32x4*>(a.bias + g * H + ht * 16 + q * 4);
+    const int R = a.rows, tl = blockIdx.x;                               // one 16-row tile per workgroup
+    constexpr int CHP = 16 * H / 8;                                       // 16-byte chunks per plane (= NTHR / 2)
+    static_assert(2 * CHP == NTHR, "one chunk per thread");
+    const int spl = tid >= CHP ? 1 : 0, sc = tid - spl * CHP, sjj = sc / (H / 8), sc8 = (sc - sjj * (H / 8)) * 8;
+    const bf16x8 zero8 = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+    {
+        const int r = tl * 16 + sjj;
+        *reinterpret_cast<bf16x8*>(img + spl * IMG + ((sc8 / KQ) * 16 + sjj) * RS + (sc8 % KQ)) =
+            r < R ? *reinterpret_cast<const bf16x8*>((spl ? a.in_lo : a.in_hi) + (size_t)r * H + sc8) : zero8;
+    }
+    __syncthreads();
+    const bf16_t* rh = img + (q * 16 + j) * RS;
+    f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(rh + 8 * s);
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(rh + IMG + 8 * s);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            acc[g] = mfma_bf16_16x16x32(whi[g][s], bh, acc[g]);
+            acc[g] = mfma_bf16_16x16x32(wlo[g][s], bh, acc[g]);
+            acc[g] = mfma_bf16_16x16x32(whi[g][s], bl, acc[g]);
+        }
+    }
+    const int r = tl * 16 + j;                                            // accumulator column j = tile row j
+    if (r < R) {
+        f32x4* dst = reinterpret_cast<f32x4*>(a.out) + ((size_t)(r >> 2) * NW + ht) * 64 + q * 16 + (r & 3);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+            dst[rr * 4] = f32x4{acc[0][rr] + bias4[0][rr], acc[1][rr] + bias4[1][rr], acc[2][rr] + bias4[2][rr], acc[3][rr] + bias4[3][rr]};
+    }
+}
+
 // dx[r][k] = sum_m dpre[r][m] W_ih[m][k] for every row at once (the time-parallel half of BPTT), three products per fragment;
 // output in MFMA fragment order (read by lstm_bwd_sp_kernel<DH = 1>); the inter-layer dropout mask of the layer input is re-applied.
 template <int H, bool DROP>
@@ -1231,6 +1289,11 @@ inline int tiles_per_wg_for(int n_tiles) { return n_tiles >= 2048 ? 8 : 1; }
 
 template <int H>
 int launch_xproj_h(const XprojArgsS& a, hipStream_t s) {
+    if (a.pair_bf16) {                                    // bf16-pair operands (constant-input layer): one 16-row tile per workgroup
+        SHM_LAUNCH((xproj_pair_sp_kernel<H>), dim3(ceil_div(a.rows, 16)), dim3(4 * H), 0, s, a);
+        SHM_LAUNCH_CHECK();
+        return SHM_OK;
+    }
     const int n_tiles = a.cpt > 0 ? a.n_chunk_tiles : ceil_div(a.rows, 16), tpw = tiles_per_wg_for(n_tiles), grid = ceil_div(n_tiles, tpw);
     if (a.drop_p > 0.f) SHM_LAUNCH((xproj_sp_kernel<H, true>), dim3(grid), dim3(4 * H), 0, s, a, tpw);
     else SHM_LAUNCH((xproj_sp_kernel<H, false>), dim3(grid), dim3(4 * H), 0, s, a, tpw);
@@ -1329,6 +1392,7 @@ int launch_lstm_bwd_dx_pair_sp(int H, const LstmBwdDxPairArgsS& a0, hipStream_t 
 int launch_xproj_sp(int H, const XprojArgsS& a, hipStream_t s) {
     SHM_REQUIRE(a.rows > 0 && a.in_hi && a.in_lo && a.W_hi && a.W_lo && a.bias && a.out, SHM_EINVAL, "xproj_sp: operand missing");
     SHM_REQUIRE(!(a.drop_p > 0.f) || (a.xd_hi && a.xd_lo), SHM_EINVAL, "xproj_sp: dropout needs the masked-input planes");
+    SHM_REQUIRE(!a.pair_bf16 || (a.drop_p == 0.f && a.cpt == 0), SHM_EINVAL, "xproj_sp: the bf16-pair form serves whole, undropped inputs only");
     SHM_DISPATCH_H(launch_xproj_h, "xproj_sp")
 }
 int launch_dx_sp(int H, const DxArgsS& a, hipStream_t s) {

@@ -37,18 +37,18 @@ def lstm_layer(xin, pre, l, mode, const=False):
     return out,hn
 def fwd(mode):
     o0,_=lstm_layer(x,'encoder_lstm',0,None)
-    o1,hn=lstm_layer(o0,'encoder_lstm',1,mode)
+    o1,hn=lstm_layer(o0,'encoder_lstm',1,mode.replace('-dec0exact',''))
     h=F.layer_norm(hn[-1],(H,),P['layer_norm.weight'],P['layer_norm.bias'],1e-5)
     mu=F.linear(h,P['fc_mu.weight'],P['fc_mu.bias']); lv=F.linear(h,P['fc_logvar.weight'],P['fc_logvar.bias'])
     z=mu+eps*torch.exp(0.5*lv)
     h0=torch.tanh(F.linear(z,P['fc_latent_to_hidden.weight'],P['fc_latent_to_hidden.bias']))
     xin=h0.unsqueeze(1).repeat(1,x.size(1),1)
-    d0,_=lstm_layer(xin,'decoder_lstm',0,mode)
-    d1,_=lstm_layer(d0,'decoder_lstm',1,mode)
+    d0,_=lstm_layer(xin,'decoder_lstm',0,'exact' if mode.endswith('-dec0exact') else mode)
+    d1,_=lstm_layer(d0,'decoder_lstm',1,mode.replace('-dec0exact',''))
     rec=F.linear(d1,P['output_layer.weight'],P['output_layer.bias'])
     return rec,mu,lv
 with torch.no_grad():
-    for mode in ['exact','f16+8','f16only','bf16+8']:
+    for mode in ['exact','f16+8','f16+8-dec0exact','f16only','bf16+8']:
         rec,mu,lv=fwd(mode)
         sc=((rec-x)**2).mean(dim=(1,2)).numpy()
         print(f"{mode:8s} recon {np.abs(rec.numpy()-d['recon']).max():.2e} mu {np.abs(mu.numpy()-d['mu']).max():.2e} lv {np.abs(lv.numpy()-d['logvar']).max():.2e} score {np.abs(sc-d['score']).max():.2e}")
