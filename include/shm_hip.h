@@ -34,7 +34,7 @@ extern "C" {
 
 /* SHM_PREC_SPLIT: every MFMA operand is a pair of bf16 values hi + lo (16 significant bits), products hi*hi + hi*lo + lo*hi in fp32:
  * holds the reference's fp32 results to ~1e-6 (the 1e-4 parity bar) at bf16 matrix rates — the fast parity path.  Since round 3 the
- * forward input projections W_ih x of layers whose input is a hidden vector use W_ih ~ fp16(W) + e4m3((W - fp16 W) 2^15) 2^-15 (15
+ * forward input projections W_ih x of layers whose input is a hidden SEQUENCE (layers >= 1) use W_ih ~ fp16(W) + e4m3((W - fp16 W) 2^15) 2^-15 (15
  * significant bits, measured at the same 5e-6 level) with x as an fp16 pair + e4m3: that W_ih fits a CU beside W_hh, which lets both
  * layers of a stack run as one layer-pipelined launch. */
 enum { SHM_PREC_F32 = 0, SHM_PREC_BF16 = 1, SHM_PREC_SPLIT = 2 };
