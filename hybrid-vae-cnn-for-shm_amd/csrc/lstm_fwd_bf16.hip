@@ -59,14 +59,22 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint3
 template <int H, int XK, bool XF32, bool DROP, bool CONSTIN, bool SAVE, bool CONSUME, bool PRODUCE>
 __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int tile, gu32* flag_in, gu32* flag_out, gu32* err) {
     static_assert(!CONSUME || (!XF32 && !CONSTIN), "a consumer reads the bf16 h_seq of the layer below");
+    static_assert(!(PRODUCE && !XF32 && !CONSTIN), "a producer is a layer-0 role (fp32 or constant input)");
     constexpr int NW = H / 16, NTHR = 64 * NW;
     constexpr int KSH = H / 32;                 // k-steps of the recurrent operand
     constexpr int KQH = H / 4, RSH = lds_row_stride(KQH);
     constexpr int KQX = XK * 8, RSX = lds_row_stride(KQX);
     constexpr int HBUF = 4 * 16 * RSH, XBUF = 4 * 16 * RSX;       // bf16 elements per operand image
+    // GRP (bf16 sequence input, layers >= 1): the input projection is formed FOUR STEPS PER MFMA TILE — the 16 columns of the B operand
+    // are 4 steps x 4 windows (row 4s + w of the x image of a group), so a group costs 4*XK input MFMAs instead of 16*XK.  The
+    // recurrent product must then land in columns 4s..4s+3 at step s = t & 3: the h image of step t keeps its 4 windows in rows
+    // 4s..4s+3 (one image per s, so the other rows of an image are never written and stay zero), and the re-deal takes its
+    // source lanes from that column group.  Per output element the MFMA sequence is unchanged (bias, W_ih k-steps, W_hh k-steps).
+    constexpr bool GRP = !XF32 && !CONSTIN;
+    constexpr int NHB = GRP ? 4 : 2;
     extern __shared__ __attribute__((aligned(16))) bf16_t smem_b[];
-    bf16_t* h_lds = smem_b;                     // [2][HBUF]
-    bf16_t* x_lds = smem_b + 2 * HBUF;          // [2][XBUF]
+    bf16_t* h_lds = smem_b;                     // [NHB][HBUF]
+    bf16_t* x_lds = smem_b + NHB * HBUF;        // [2][XBUF]
 
     const int In = a.In, T = a.T, B = a.B;
     const int tid = threadIdx.x, lane = tid & 63, ht = tid >> 6, q = lane >> 4, j = lane & 15;
@@ -75,7 +83,7 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int t
     const int cb = tile * WPT + cj;
     const bool cvalid = cb < B;
 
-    for (int e = tid; e < 2 * (HBUF + XBUF); e += NTHR) smem_b[e] = (bf16_t)0.f;
+    for (int e = tid; e < NHB * HBUF + 2 * XBUF; e += NTHR) smem_b[e] = (bf16_t)0.f;
 
     // ---- weights -> registers (fragment order, see kernels.hpp)
     bf16x8 wh[4][KSH], wx[4][XK];
@@ -151,8 +159,8 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int t
             X.e = reinterpret_cast<const unsigned short*>(a.in)[((size_t)tile * T + tc) * WPT * H + tid];
         }
     };
-    auto x_commit = [&](XSlot& X, int t, int buf) {      // t: the step the slot holds
-        bf16_t* xl = x_lds + buf * XBUF;
+    auto x_commit = [&](XSlot& X, int t, int buf) {      // t: the step the slot holds (GRP: the image and row follow from t)
+        bf16_t* xl = GRP ? x_lds + ((t >> 2) & 1) * XBUF + (t & 3) * 4 * RSX : x_lds + buf * XBUF;
         if constexpr (XF32) {
             asm volatile("" : "+v"(X.s0));                 // pin the use (see lstm_bwd_bf16.hip)
             if (tid < WPT * In) {
@@ -194,13 +202,19 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int t
     // accumulator lanes (q, j<4, r=0..3) -> cell lanes (q, jj): one float per gate.  Lane jj of a 16-lane row takes register
     // jj>>2 of lane jj&3: three DPP moves per gate (row_shr:4r written only to lanes 4r..4r+3 through the bank mask) instead of
     // an LDS round trip — measured 0.17 us of every ~1 us step when it went through LDS (ablation, round 1).
-    auto redeal = [&](const f32x4 (&acc)[4], float (&gate)[4]) {
+    // S: the column group (lanes 4S..4S+3 of each row) that holds the step's windows (0 unless GRP): lane jj takes register r = jj>>2
+    // of lane 4S + (jj&3), i.e. row_shr:4(r-S) for r > S, row_shl:4(S-r) for r < S, its own register for r == S.
+    auto redeal = [&](auto sc, const f32x4 (&acc)[4], float (&gate)[4]) {
+        constexpr int S = decltype(sc)::value;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            int v = __float_as_int(acc[g][0]);                                            // lanes 0..3 of each row already hold r = 0
-            v = __builtin_amdgcn_update_dpp(v, __float_as_int(acc[g][1]), 0x114, 0xF, 0x2, false);   // row_shr:4  -> lanes 4..7
-            v = __builtin_amdgcn_update_dpp(v, __float_as_int(acc[g][2]), 0x118, 0xF, 0x4, false);   // row_shr:8  -> lanes 8..11
-            v = __builtin_amdgcn_update_dpp(v, __float_as_int(acc[g][3]), 0x11C, 0xF, 0x8, false);   // row_shr:12 -> lanes 12..15
+            int v = __float_as_int(acc[g][S]);
+            if constexpr (S != 0) v = __builtin_amdgcn_update_dpp(v, __float_as_int(acc[g][0]), 0x100 + 4 * (S > 0 ? S : 1), 0xF, 0x1, false);
+            if constexpr (S < 1) v = __builtin_amdgcn_update_dpp(v, __float_as_int(acc[g][1]), 0x110 + 4 * (S < 1 ? 1 - S : 1), 0xF, 0x2, false);
+            if constexpr (S > 1) v = __builtin_amdgcn_update_dpp(v, __float_as_int(acc[g][1]), 0x100 + 4 * (S > 1 ? S - 1 : 1), 0xF, 0x2, false);
+            if constexpr (S < 2) v = __builtin_amdgcn_update_dpp(v, __float_as_int(acc[g][2]), 0x110 + 4 * (S < 2 ? 2 - S : 1), 0xF, 0x4, false);
+            if constexpr (S > 2) v = __builtin_amdgcn_update_dpp(v, __float_as_int(acc[g][2]), 0x100 + 4 * (S > 2 ? S - 2 : 1), 0xF, 0x4, false);
+            if constexpr (S != 3) v = __builtin_amdgcn_update_dpp(v, __float_as_int(acc[g][3]), 0x110 + 4 * (S < 3 ? 3 - S : 1), 0xF, 0x8, false);
             gate[g] = __int_as_float(v);
         }
     };
@@ -221,6 +235,19 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int t
 #pragma unroll
         for (int g = 0; g < 4; ++g) xproj[g] = bias4[g];
         mma_x(xproj, x_lds);
+    } else if constexpr (GRP) {
+        XSlot P0, P1, P2, P3;                              // group 0 (steps 0..3) and x_4, which step 0 no longer has time to commit
+        x_fetch(P0, 0); x_fetch(P1, 1); x_fetch(P2, 2); x_fetch(P3, 3);
+        x_commit(P0, 0, 0);
+        if (T > 1) x_commit(P1, 1, 0);
+        if (T > 2) x_commit(P2, 2, 0);
+        if (T > 3) x_commit(P3, 3, 0);
+        x_fetch(P0, 4);
+        if (T > 4) x_commit(P0, 4, 0);
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xproj[g] = bias4[g];
+        mma_x(xproj, x_lds);                               // group 0's input projection
     } else {
         XSlot X;
         x_fetch(X, 0);
@@ -238,8 +265,12 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int t
 
     // vector-memory instructions wave 0 issues per step besides the flag store (h_seq, record, x prefetch, masked x)
     constexpr int OPS = 1 + (SAVE ? 1 : 0) + (CONSTIN ? 0 : 1) + (DROP ? 1 : 0);
-    auto h_flush = [&](int t_done, int buf) {
-        if (tid < NCH) {
+    auto h_flush = [&](int t_done, int buf) {            // GRP: buf = (t_done + 1) & 3 and the windows sit in rows 4 * buf ..
+        if constexpr (GRP) {
+            if (tid < NCH)
+                *reinterpret_cast<bf16x8*>(a.h_seq + ((size_t)tile * T + t_done) * WPT * H + (size_t)xc * 8) =
+                    *reinterpret_cast<const bf16x8*>(h_lds + buf * (HBUF + 4 * RSH) + h_img_off);
+        } else if (tid < NCH) {
             if constexpr (PRODUCE) {
                 const u32x4 v = *reinterpret_cast<const u32x4*>(h_lds + buf * HBUF + h_img_off);
                 __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, (uint32_t)(t_done * WPT * H + xc * 8) * 2, 0, 16);
@@ -256,8 +287,10 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int t
     u32x3 rec_prev = {{0u, 0u, 0u}};
     // X: slot holding x_{t+2}; committed at the end of the step (into the buffer of x_t, whose projection step t-1 consumed)
     // and refilled with x_{t+5}
-    auto step = [&](XSlot& X, int t) {
-        const int cur = t & 1;
+    auto step = [&](auto sc, XSlot& X, int t) {         // sc: t & 3 (GRP) or 0
+        constexpr int S = decltype(sc)::value;
+        const int cur = GRP ? S : t & 1;                   // GRP: image S holds h_{t-1} in rows 4S.., image (S+1)&3 receives h_t
+        constexpr int NXT = (S + 1) & 3;
         if (t > 0) h_flush(t - 1, cur);                    // h_{t-1} sits complete in h_lds[cur]
         f32x4 acc[4];
 #pragma unroll
@@ -273,7 +306,10 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int t
         if constexpr (SAVE) {
             if (t > 0) sv[(size_t)(t - 1) * NW * 64] = rec_prev;
         }
-        if constexpr (!CONSTIN) {
+        if constexpr (GRP) {                               // x_{4G+7} must be in the image before step 4G+3 forms group G+1's projection
+            if (t + 5 < T) x_commit(X, t + 5, 0);
+            x_fetch(X, t + 9);
+        } else if constexpr (!CONSTIN) {
             if (t + 2 < T) x_commit(X, t + 2, cur);
             x_fetch(X, t + 5);
         }
@@ -285,13 +321,16 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int t
         __builtin_amdgcn_sched_barrier(0);
 
         float gate[4];
-        redeal(acc, gate);
+        redeal(sc, acc, gate);
         // Cell update, hand-interleaved with next step's input MFMAs (x_{t+1}, buffer cur^1, in LDS since the last barrier):
         // two MFMAs between each group of vector instructions, the order pinned with sched_barrier — left to itself the
         // compiler issues the MFMAs as one block in front of the transcendentals.
+        // GRP: the whole projection of the next group is formed in the group's last step (its x rows were committed up to step t - 1),
+        // the other three steps carry no input MFMAs
+        constexpr bool XM = !CONSTIN && (!GRP || S == 3);
         bf16x8 bx[XK > 0 ? XK : 1];
-        if constexpr (!CONSTIN) {
-            const bf16_t* row = x_lds + (cur ^ 1) * XBUF + (q * 16 + j) * RSX;
+        if constexpr (XM) {
+            const bf16_t* row = x_lds + (GRP ? ((t >> 2) + 1) & 1 : cur ^ 1) * XBUF + (q * 16 + j) * RSX;
 #pragma unroll
             for (int sx = 0; sx < XK; ++sx) bx[sx] = *reinterpret_cast<const bf16x8*>(row + 8 * sx);
 #pragma unroll
@@ -299,7 +338,7 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int t
         }
         auto xm = [&](auto ic) {                           // input MFMAs number 2i, 2i+1 (k-step major, gates 0..3 inner)
             constexpr int I = decltype(ic)::value;
-            if constexpr (!CONSTIN) {
+            if constexpr (XM) {
 #pragma unroll
                 for (int k = 2 * I; k < 2 * I + 2; ++k)
                     if (k < 4 * XK) xproj[k & 3] = mfma_bf16_16x16x32(wx[k & 3][k >> 2], bx[k >> 2], xproj[k & 3]);
@@ -334,7 +373,8 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int t
         h = go * tc;
         __builtin_amdgcn_sched_barrier(0);
         xm(IntC<7>{});
-        h_lds[(cur ^ 1) * HBUF + my_h_off] = (bf16_t)h;
+        if constexpr (GRP) h_lds[NXT * (HBUF + 4 * RSH) + my_h_off] = (bf16_t)h;
+        else h_lds[(cur ^ 1) * HBUF + my_h_off] = (bf16_t)h;
         if constexpr (SAVE) {                              // stored at the start of the next step (or after the loop)
             f32x2 a0 = {gi, gf}, a1 = {gg, go};
             rec_prev[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(a0, bf16x2));
@@ -344,18 +384,33 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int t
         }
         __syncthreads();
     };
-    XSlot X0, X1, X2;
     int t = 0;
-    for (int k = T % 3; k > 0; --k, ++t) { x_fetch(X0, t + 2); step(X0, t); }   // peel: the main loop runs whole triples
-    x_fetch(X0, t + 2); x_fetch(X1, t + 3); x_fetch(X2, t + 4);
-    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0) once: only steady-state loads cross the back-edge
-    for (; t + 2 < T; t += 3) {
-        step(X0, t);
-        step(X1, t + 1);
-        step(X2, t + 2);
+    if constexpr (GRP) {
+        XSlot X0, X1, X2, X3;                              // slot t & 3 holds x_{t+5} at the top of step t
+        x_fetch(X0, 5); x_fetch(X1, 6); x_fetch(X2, 7); x_fetch(X3, 8);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0) once: only steady-state loads cross the back-edge
+        for (; t + 3 < T; t += 4) {
+            step(IntC<0>{}, X0, t);
+            step(IntC<1>{}, X1, t + 1);
+            step(IntC<2>{}, X2, t + 2);
+            step(IntC<3>{}, X3, t + 3);
+        }
+        if (t < T) { step(IntC<0>{}, X0, t); ++t; }        // T % 4 steps of a last, partial group (its projection exists already)
+        if (t < T) { step(IntC<1>{}, X1, t); ++t; }
+        if (t < T) { step(IntC<2>{}, X2, t); ++t; }
+    } else {
+        XSlot X0, X1, X2;
+        for (int k = T % 3; k > 0; --k, ++t) { x_fetch(X0, t + 2); step(IntC<0>{}, X0, t); }   // peel: the main loop runs whole triples
+        x_fetch(X0, t + 2); x_fetch(X1, t + 3); x_fetch(X2, t + 4);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0) once: only steady-state loads cross the back-edge
+        for (; t + 2 < T; t += 3) {
+            step(IntC<0>{}, X0, t);
+            step(IntC<0>{}, X1, t + 1);
+            step(IntC<0>{}, X2, t + 2);
+        }
     }
     if constexpr (SAVE) sv[(size_t)(T - 1) * NW * 64] = rec_prev;
-    h_flush(T - 1, T & 1);                                 // the last image (buffer T&1; its barrier has passed)
+    h_flush(T - 1, GRP ? T & 3 : T & 1);                   // the last image (its barrier has passed)
     if constexpr (PRODUCE) {
         if (tid < NCH) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -405,7 +460,7 @@ __global__ void __launch_bounds__(4 * H) lstm_fwd_pair_bf16_kernel(LstmFwdPairAr
 template <int H, int XK, bool XF32, bool CONSTIN>
 int launch_x(const LstmFwdArgsB& a, hipStream_t s) {
     const int tiles = ceil_div(a.B, WPT);
-    const size_t lds = sizeof(bf16_t) * 2 * 4 * 16 * (lds_row_stride(H / 4) + lds_row_stride(XK * 8)) + sizeof(float) * (H / 16) * 256;
+    const size_t lds = sizeof(bf16_t) * 4 * 16 * (4 * lds_row_stride(H / 4) + 2 * lds_row_stride(XK * 8)) + sizeof(float) * (H / 16) * 256;   // four h images (GRP), two x images
     const bool drop = a.drop_p > 0.f && !XF32 && !CONSTIN, save = a.sv_g != nullptr;
     void (*kern)(LstmFwdArgsB);
     if constexpr (XF32 || CONSTIN)
@@ -449,7 +504,7 @@ int launch_pair_h(const LstmFwdPairArgsB& p0, hipStream_t s) {
     const bool drop = b.drop_p > 0.f, save = a.sv_g != nullptr;
     SHM_REQUIRE(!drop || b.xdrop, SHM_EINVAL, "lstm_fwd_pair: dropout needs the xdrop buffer");
     const int tiles = ceil_div(a.B, WPT);
-    const size_t lds = sizeof(bf16_t) * 2 * 4 * 16 * (lds_row_stride(H / 4) + lds_row_stride(H / 4)) + sizeof(float) * (H / 16) * 256;
+    const size_t lds = sizeof(bf16_t) * 4 * 16 * (4 * lds_row_stride(H / 4) + 2 * lds_row_stride(H / 4)) + sizeof(float) * (H / 16) * 256;
     p.role_lds_off = (int)lds;
     void (*kern)(LstmFwdPairArgsB);
     if (xf32) kern = drop ? (save ? lstm_fwd_pair_bf16_kernel<H, true, true, true> : lstm_fwd_pair_bf16_kernel<H, true, true, false>)
