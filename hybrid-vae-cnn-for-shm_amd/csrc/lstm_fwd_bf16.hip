@@ -59,18 +59,17 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint3
 template <int H, int XK, bool XF32, bool DROP, bool CONSTIN, bool SAVE, bool CONSUME, bool PRODUCE>
 __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int tile, gu32* flag_in, gu32* flag_out, gu32* err) {
     static_assert(!CONSUME || (!XF32 && !CONSTIN), "a consumer reads the bf16 h_seq of the layer below");
-    static_assert(!(PRODUCE && !XF32 && !CONSTIN), "a producer is a layer-0 role (fp32 or constant input)");
     constexpr int NW = H / 16, NTHR = 64 * NW;
     constexpr int KSH = H / 32;                 // k-steps of the recurrent operand
     constexpr int KQH = H / 4, RSH = lds_row_stride(KQH);
     constexpr int KQX = XK * 8, RSX = lds_row_stride(KQX);
     constexpr int HBUF = 4 * 16 * RSH, XBUF = 4 * 16 * RSX;       // bf16 elements per operand image
-    // GRP (bf16 sequence input, layers >= 1): the input projection is formed FOUR STEPS PER MFMA TILE — the 16 columns of the B operand
+    // GRP (every layer with a time-varying input): the input projection is formed FOUR STEPS PER MFMA TILE — the 16 columns of the B operand
     // are 4 steps x 4 windows (row 4s + w of the x image of a group), so a group costs 4*XK input MFMAs instead of 16*XK.  The
     // recurrent product must then land in columns 4s..4s+3 at step s = t & 3: the h image of step t keeps its 4 windows in rows
     // 4s..4s+3 (one image per s, so the other rows of an image are never written and stay zero), and the re-deal takes its
     // source lanes from that column group.  Per output element the MFMA sequence is unchanged (bias, W_ih k-steps, W_hh k-steps).
-    constexpr bool GRP = !XF32 && !CONSTIN;
+    constexpr bool GRP = !CONSTIN;
     constexpr int NHB = GRP ? 4 : 2;
     extern __shared__ __attribute__((aligned(16))) bf16_t smem_b[];
     bf16_t* h_lds = smem_b;                     // [NHB][HBUF]
@@ -266,21 +265,17 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int t
     // vector-memory instructions wave 0 issues per step besides the flag store (h_seq, record, x prefetch, masked x)
     constexpr int OPS = 1 + (SAVE ? 1 : 0) + (CONSTIN ? 0 : 1) + (DROP ? 1 : 0);
     auto h_flush = [&](int t_done, int buf) {            // GRP: buf = (t_done + 1) & 3 and the windows sit in rows 4 * buf ..
-        if constexpr (GRP) {
-            if (tid < NCH)
-                *reinterpret_cast<bf16x8*>(a.h_seq + ((size_t)tile * T + t_done) * WPT * H + (size_t)xc * 8) =
-                    *reinterpret_cast<const bf16x8*>(h_lds + buf * (HBUF + 4 * RSH) + h_img_off);
-        } else if (tid < NCH) {
+        if (tid < NCH) {
+            const bf16_t* src = h_lds + buf * (GRP ? HBUF + 4 * RSH : HBUF) + h_img_off;
             if constexpr (PRODUCE) {
-                const u32x4 v = *reinterpret_cast<const u32x4*>(h_lds + buf * HBUF + h_img_off);
+                const u32x4 v = *reinterpret_cast<const u32x4*>(src);
                 __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, (uint32_t)(t_done * WPT * H + xc * 8) * 2, 0, 16);
                 // in-order vmcnt: with at most (DLY-1)*OPS younger operations outstanding, the h_seq store of step
                 // t_done - DLY + 1 ... has retired; publish one step more conservatively than that
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DLY - 1) * OPS) : "memory");
                 if (tid == 0 && t_done >= DLY) __hip_atomic_store(flag_out, (unsigned)(t_done - DLY + 1), SHM_RLX_AGENT);
             } else {
-                *reinterpret_cast<bf16x8*>(a.h_seq + ((size_t)tile * T + t_done) * WPT * H + (size_t)xc * 8) =
-                    *reinterpret_cast<const bf16x8*>(h_lds + buf * HBUF + h_img_off);
+                *reinterpret_cast<bf16x8*>(a.h_seq + ((size_t)tile * T + t_done) * WPT * H + (size_t)xc * 8) = *reinterpret_cast<const bf16x8*>(src);
             }
         }
     };
