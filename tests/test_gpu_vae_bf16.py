@@ -151,10 +151,14 @@ def test_bf16_layer_pipelined_launch_is_bit_identical(train_mode):
     from shm_hip._capi import lib
     from shm_hip.trainer import VAETrainer
     # incl. degenerate lengths: T < the hand-off delay (4), T < one 4-step dx chunk, a single window
-    for (B, T, H) in ((512, 256, 128), (510, 100, 128), (37, 50, 64), (9, 31, 32), (1, 1, 128), (3, 2, 128), (5, 3, 64), (2, 5, 32), (4, 7, 128),
-                      (1100, 20, 128)):      # 275 tiles: three ticket groups, the last one partial
+    # T % 4 == 0 takes the second form of the backward pair launch (dx formed by the top layer, chunk by chunk), anything else the first;
+    # the forward groups its input projection four steps per tile at every length.  drop: both dropout template variants.
+    for (B, T, H, drop) in ((512, 256, 128, 0.3), (510, 100, 128, 0.3), (37, 50, 64, 0.3), (9, 31, 32, 0.3), (1, 1, 128, 0.3), (3, 2, 128, 0.3),
+                            (5, 3, 64, 0.3), (2, 5, 32, 0.3), (4, 7, 128, 0.3), (37, 48, 64, 0.3), (9, 32, 32, 0.3), (6, 4, 128, 0.3), (5, 8, 64, 0.0),
+                            (3, 4, 32, 0.3), (13, 12, 128, 0.0), (64, 40, 128, 0.0),
+                            (1100, 20, 128, 0.3)):      # 275 tiles: three ticket groups, the last one partial
         torch.manual_seed(11)
-        m = TemporalVAE(4, 16, H, 2, 0.3, precision="bf16").cuda()
+        m = TemporalVAE(4, 16, H, 2, drop, precision="bf16").cuda()
         gen = torch.Generator().manual_seed(B)
         x = torch.randn(B, T, 4, generator=gen).cuda()
         eps = torch.randn(B, 16, generator=gen).cuda()
@@ -164,7 +168,7 @@ def test_bf16_layer_pipelined_launch_is_bit_identical(train_mode):
             try:
                 if train_mode:
                     torch.manual_seed(11)
-                    m2 = TemporalVAE(4, 16, H, 2, 0.3, precision="bf16").cuda().train()
+                    m2 = TemporalVAE(4, 16, H, 2, drop, precision="bf16").cuda().train()
                     tr = VAETrainer(m2, lr=1e-3, weight_decay=1e-5, max_norm=2.0)
                     stats = tr.step(x, 0.3, eps=eps, drop_seed=99)
                     out = (stats.clone(), tr.grads.clone())
