@@ -142,6 +142,23 @@ __host__ __device__ __forceinline__ float eps_normal(uint64_t seed, uint64_t off
     return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
 }
 
+// Polling a progress word of an in-launch hand-off (pair launches).  The word is wave-uniform, so it is read with a SCALAR load (glc: served
+// by L2, not by the scalar cache), which waits on lgkmcnt: a poll then does not drain the wave's vector-memory queue.  With a vector load
+// (vmcnt retires in order) every poll waited for all the record / operand prefetches in flight, and a role that had caught up with its
+// producer emptied its prefetch queue once per hand-off chunk (bf16 backward pair 0.222 -> 0.216 ms per launch with the scalar form).
+// uniform_addr: the word's address in an SGPR pair (the readfirstlane builtin returns int: cast before widening, or a low half with bit
+// 31 set sign-extends into the high half — a wild address).
+__device__ __forceinline__ uint64_t uniform_addr(const void* p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
+           (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+}
+__device__ __forceinline__ unsigned poll_uniform(uint64_t addr_s) {
+    unsigned v;
+    asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(addr_s) : "memory");
+    return v;
+}
+
 __host__ __device__ __forceinline__ int ceil_div(int a, int b) { return (a + b - 1) / b; }
 __host__ __device__ __forceinline__ int round_up(int a, int b) { return ceil_div(a, b) * b; }
 

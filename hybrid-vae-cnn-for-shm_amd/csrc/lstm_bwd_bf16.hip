@@ -51,19 +51,6 @@ __device__ __forceinline__ float redeal1(const f32x4 a) {
     return __int_as_float(v);
 }
 
-// S-variant (pair launch, dx formed by the top layer): the step's windows sit in columns 4S..4S+3 of the accumulator (see lstm_fwd_bf16.hip)
-template <int S>
-__device__ __forceinline__ float redeal1s(const f32x4 a) {
-    int v = __float_as_int(a[S]);
-    if constexpr (S != 0) v = __builtin_amdgcn_update_dpp(v, __float_as_int(a[0]), 0x100 + 4 * (S > 0 ? S : 1), 0xF, 0x1, false);
-    if constexpr (S < 1) v = __builtin_amdgcn_update_dpp(v, __float_as_int(a[1]), 0x110 + 4 * (S < 1 ? 1 - S : 1), 0xF, 0x2, false);
-    if constexpr (S > 1) v = __builtin_amdgcn_update_dpp(v, __float_as_int(a[1]), 0x100 + 4 * (S > 1 ? S - 1 : 1), 0xF, 0x2, false);
-    if constexpr (S < 2) v = __builtin_amdgcn_update_dpp(v, __float_as_int(a[2]), 0x110 + 4 * (S < 2 ? 2 - S : 1), 0xF, 0x4, false);
-    if constexpr (S > 2) v = __builtin_amdgcn_update_dpp(v, __float_as_int(a[2]), 0x100 + 4 * (S > 2 ? S - 2 : 1), 0xF, 0x4, false);
-    if constexpr (S != 3) v = __builtin_amdgcn_update_dpp(v, __float_as_int(a[3]), 0x110 + 4 * (S < 3 ? 3 - S : 1), 0xF, 0x8, false);
-    return __int_as_float(v);
-}
-
 struct Prefetch {            // operands of one time step of this lane's cell, fetched PD = 3 steps ahead
     u32x3 rec;               // {i,f | g,o | c_{t-1}, tanh(c_t)} (bf16x2 each) written by the forward
     f32x4 up;                // DH == 1: up[0] = dx of this cell;  DH == 2: dy[b,t,0..3] (raw, multiplied by W_out at use)
@@ -76,15 +63,8 @@ struct Prefetch {            // operands of one time step of this lane's cell, f
 // The time loop is branch-free: loads are clamped, never predicated, and T % 3 steps are peeled, so that the compiler can
 // count the loads in flight across the back-edge instead of draining them (s_waitcnt vmcnt(0)) at every loop header.
 // PRODUCE: dpre_seq is consumed by the layer-0 workgroup of the same tile inside this launch (flag_out).
-// PF (second form of the pair launch, T % 4 == 0): 1 = top layer that also forms dx = dpre W_ih for the layer below, a 4-step chunk
-// (16 MFMA columns = 4 steps x 4 windows) at a time, out of its OWN operand images: the image of a chunk keeps step s = t & 3 in rows
-// 4s..4s+3 (the recurrent product then lands in columns 4s..4s+3; what the other columns hold is never read), so after the chunk's
-// four steps it IS the B operand of the chunk's dx tile.  The 4H/32 MFMAs of chunk c are spread over the four steps of chunk c-1, dx
-// leaves in dx_gemm's fragment order with write-through stores, and "chunks >= c are in memory" is published one chunk later behind a
-// counted vmcnt.  2 = the layer below: the plain DH == 1 recurrence reading that dx with sc1 loads behind the progress word (flag).
-template <int H, int DH, bool PRODUCE, int PF = 0, bool DROP = false>
-__device__ __forceinline__ void lstm_bwd_body(const LstmBwdArgsB& a, const int tile, gu32* flag_out, gu32* err = nullptr) {
-    static_assert(!(PRODUCE && PF != 0) && (PF != 2 || DH == 1), "one hand-off form per launch");
+template <int H, int DH, bool PRODUCE>
+__device__ __forceinline__ void lstm_bwd_body(const LstmBwdArgsB& a, const int tile, gu32* flag_out) {
     constexpr int NW = H / 16, NTHR = 64 * NW;
     constexpr int KS = H / 8;                      // k-steps of 32 over K = 4H
     constexpr int RS = lds_row_stride(H);          // quarter q <-> gate q, KQ = H
@@ -117,51 +97,6 @@ __device__ __forceinline__ void lstm_bwd_body(const LstmBwdArgsB& a, const int t
         for (int s = 0; s < KS; ++s) whT[s] = p[s * 64];
     }
 
-    // PF == 1: W_ih^T fragments of the dx product.  At H = 128 all but two k-steps live in LDS ([k-step][wave][lane], 112 KB): with all 64
-    // VGPRs of them beside W_hh^T the compiler had no registers left to keep the recurrent product's operand reads in flight (it waited
-    // for one pair of LDS reads at a time, on the step's critical path); the dx product is off that path and reads its A operand from LDS.
-    constexpr int WXL = (PF == 1 && H == 128) ? KS - 2 : 0, WXR = PF == 1 ? KS - WXL : 1;
-    bf16x8 wxT[WXR];
-    bf16x8* wx_lds = reinterpret_cast<bf16x8*>(wo_lds + (DH >= 2 ? Dy * H : 0));       // behind wo_lds ([Dy][H] floats; H % 32 == 0 keeps 16-byte alignment)
-    if constexpr (PF == 1) {
-        const bf16x8* px = reinterpret_cast<const bf16x8*>(a.WxT) + (size_t)ht * KS * 64 + lane;
-#pragma unroll
-        for (int s = 0; s < WXL; ++s) wx_lds[(s * NW + ht) * 64 + lane] = px[s * 64];
-#pragma unroll
-        for (int s = WXL; s < KS; ++s) wxT[s - WXL] = px[s * 64];
-    }
-    auto wx_frag = [&](int ks) -> bf16x8 { return ks < WXL ? wx_lds[(ks * NW + ht) * 64 + lane] : wxT[ks - WXL < 0 ? 0 : ks - WXL]; };
-    const uint32_t thr = drop_threshold(a.drop_p);
-    const float dscale = DROP ? 1.0f / (1.0f - a.drop_p) : 1.0f;
-    const int NC = T >> 2;                                             // PF: chunks of the window
-    // the tile's block of dx in dx_gemm's fragment order: fragment (tile*T/4 + c), [wave][lane][4]
-    const size_t dx_tile = (size_t)tile * (T >> 2) * NW * 64 * 4;
-    const __amdgpu_buffer_rsrc_t dx_rsrc = make_rsrc(PF == 1 ? a.dx_seq + dx_tile : (PF == 2 ? a.dh_seq + dx_tile : nullptr),
-                                                     PF != 0 ? (uint32_t)(T >> 2) * NW * 64 * 16 : 0);
-    int avail = 0;                                                     // PF == 2, wave-uniform: chunks >= NC - avail are in memory
-    const uint64_t flag_v = reinterpret_cast<uint64_t>(flag_out);      // the progress word's address in an SGPR pair
-    const uint64_t flag_s = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(flag_v >> 32)) << 32) |
-                            (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)flag_v);      // (the builtin returns int: no sign extension)
-    auto wait_for = [&](int need) {
-        if (avail >= need) return;
-        unsigned v, spins = 0;
-#pragma clang loop unroll(disable)
-        for (;;) {
-            // The progress word is wave-uniform: polled with a SCALAR load (glc: served by L2, not by the scalar cache).  It waits on
-            // lgkmcnt, so a poll does not drain the wave's record / dx prefetches the way a vector load (in-order vmcnt) does — with the
-            // vector form a layer-0 wave that had caught up with its producer emptied its prefetch queue once per chunk.
-            asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(flag_s) : "memory");
-            if ((int)v >= need) break;
-            if (++spins > SPIN_MAX) {                                  // give up: finish with garbage, flagged in the err word
-                if (lane == 0) __hip_atomic_store(err, 0x80000001u + (unsigned)tile, SHM_RLX_AGENT);
-                v = 0x7fffffff;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(8);
-        }
-        avail = (int)v;
-    };
-
     const u32x3* sv = reinterpret_cast<const u32x3*>(a.sv_g) + ((size_t)tile * T * NW + ht) * 64 + lane;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
@@ -169,12 +104,7 @@ __device__ __forceinline__ void lstm_bwd_body(const LstmBwdArgsB& a, const int t
         const int tc = t < 0 ? 0 : t;                                  // clamp: steps < 0 are fetched but never used
         P.rec = sv[(size_t)tc * NW * 64];
         const size_t row = (size_t)bc * T + tc;                        // natural row of dy [B,T,Dy]
-        if constexpr (PF == 2) {
-            wait_for(NC - (tc >> 2));
-            P.up = zero4;
-            P.up[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                dx_rsrc, (uint32_t)((((tc >> 2) * NW + ht) * 64 + q * 16 + (tc & 3) * 4 + cj) * 4 + cr) * 4, 0, 16));
-        } else if constexpr (DH == 1) {
+        if constexpr (DH == 1) {
             // dx_gemm writes 16-row fragments: row r' = (tile*T + t)*WPT + cj sits in fragment r'/16 at lane (q, r'%16), element cr
             const size_t rp = ((size_t)tile * T + tc) * WPT + cj;
             P.up = zero4;
@@ -190,51 +120,17 @@ __device__ __forceinline__ void lstm_bwd_body(const LstmBwdArgsB& a, const int t
     float dc = 0.f, dh_rec = 0.f;
     float tsum[4] = {0.f, 0.f, 0.f, 0.f};
 
-    f32x4 dxa0 = zero4, dxa1 = zero4;                       // PF == 1: the dx tile of the chunk above, accumulated over four steps
-    constexpr int KG = KS / 4;                              // its MFMAs per step
-    bf16x8 da[PF == 1 ? KG : 1], db[PF == 1 ? KG : 1];
-    // operands of the KG MFMAs of step tn (sub-step SN): k-step group 3 - SN of image((chunk of tn) + 1) . W_ih — that image is complete
-    // since the chunk's last barrier (during the top chunk it is the zero image; nothing is stored then)
-    auto dx_operands = [&](auto snc, int tn) {
-        constexpr int SN = decltype(snc)::value;
-        if constexpr (PF == 1) {
-            const bf16_t* xrow = dp_lds + (((tn >> 2) + 1) & 1) * PBUF + (q * 16 + j) * RS;
-#pragma unroll
-            for (int i = 0; i < KG; ++i) {
-                const int ks = (3 - SN) * KG + i;
-                da[i] = wx_frag(ks);
-                db[i] = *reinterpret_cast<const bf16x8*>(xrow + 8 * ks);
-            }
-        }
-    };
-    // vector-memory operations a wave issues between two dx stores, a lower bound (four steps of record + upstream-gradient loads)
-    constexpr int OPSC = 4 * (1 + ((DH == 1 || DH == 2) ? 1 : 0));
-    // one time step; P holds this step's operands and is refilled with step t-3 once they are consumed.  sc: t & 3 (PF == 1) or 0
-    auto step = [&](auto sc, Prefetch& P, int t) {
-        constexpr int S = decltype(sc)::value;
+    // one time step; P holds this step's operands and is refilled with step t-3 once they are consumed
+    auto step = [&](Prefetch& P, int t) {
         // Pin the consumption point of this slot: without it the compiler hoists the unpacking of the LATER slots into this
         // step, i.e. touches registers whose loads are still in flight and turns the counted waits into a drain.
         asm volatile("" : "+v"(P.rec.v[0]), "+v"(P.rec.v[1]), "+v"(P.rec.v[2]), "+v"(P.up));
-        bf16_t* dpl = PF == 1 ? dp_lds + ((t >> 2) & 1) * PBUF + 4 * S * RS : dp_lds + (t & 1) * PBUF;
-        // PF == 1: k-step group 3 - S of dx(chunk above).  Its operand reads are issued here, in front of the cell update (the LDS is idle
-        // then: issued beside the recurrent product's reads they delayed every wave's), and its MFMAs in front of the step's barrier, so
-        // that they run while the workgroup meets at the barrier and the recurrent product's first operands are on their way
-        if constexpr (PF == 1) { dx_operands(sc, t); __builtin_amdgcn_sched_barrier(0); }
+        bf16_t* dpl = dp_lds + (t & 1) * PBUF;
         float dha;
-        auto dxm = [&](auto ic) {
-            constexpr int I = decltype(ic)::value, ks = (3 - S) * KG + I;
-            if constexpr (PF == 1 && I < KG) {
-                if constexpr (ks & 1) dxa1 = mfma_bf16_16x16x32(da[I], db[I], ks == 1 ? zero4 : dxa1);
-                else dxa0 = mfma_bf16_16x16x32(da[I], db[I], ks == 0 ? zero4 : dxa0);
-            }
-        };
         if constexpr (DH == 2) {
             dha = 0.f;
 #pragma unroll
             for (int dd = 0; dd < 4; ++dd) dha = fmaf(P.up[dd], wo_lds[dd * H + cu], dha);
-        } else if constexpr (PF == 2 && DROP) {            // same element index, threshold and scale as dx_gemm_bf16_kernel (a.drop_*: the layer above's)
-            const uint32_t idx = (uint32_t)((((size_t)tile * T + t) * WPT + cj) * H + cu);
-            dha = drop_hash(a.drop_seed, a.drop_stack, idx) >= thr ? P.up[0] * dscale : 0.f;
         } else dha = P.up[0];
         // bf16 -> f32 is a 16-bit shift; done on the integer words (a bf16x2 bit_cast of two different words was folded
         // into one by the compiler: both pairs came out as (i, f))
@@ -259,24 +155,10 @@ __device__ __forceinline__ void lstm_bwd_body(const LstmBwdArgsB& a, const int t
             tsum[g] += dpre[g];
         }
         fetch(P, t - 4);                                   // refill the slot: 4 steps of latency cover
-        if constexpr (PF == 1) {
-            __builtin_amdgcn_sched_barrier(0);
-            dxm(IntC<0>{}); dxm(IntC<1>{}); dxm(IntC<2>{}); dxm(IntC<3>{});
-        }
-        // in-order vmcnt: this wave's dx store of the previous chunk has retired once at most the operations issued since are outstanding —
-        // four fetches, and for the waves that copy dpre out of the image three of those stores as well (a common, smaller count would make
-        // those waves wait here for records they only need two steps later)
-        if constexpr (PF == 1 && S == 0) {
-            if (tid < WPT * 4 * H / 8) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPSC + 3) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPSC) : "memory");
-        }
         __syncthreads();
         // every storing wave has, in step t+1, waited until its dpre store of step t+DLY had retired
         if constexpr (PRODUCE) {
             if (tid == 0 && t + DLY <= T - 1) __hip_atomic_store(flag_out, (unsigned)(T - (t + DLY)), SHM_RLX_AGENT);
-        }
-        if constexpr (PF == 1 && S == 0) {                 // every wave has waited for its dx store of chunk c + 2 before this barrier
-            if (tid == 0 && (t >> 2) + 2 < NC) __hip_atomic_store(flag_out, (unsigned)(NC - ((t >> 2) + 2)), SHM_RLX_AGENT);
         }
         // dpre_t -> HBM out of the now complete image: the WPT x 4H block of (tile, t) is contiguous in dpre_seq
         {
@@ -293,7 +175,7 @@ __device__ __forceinline__ void lstm_bwd_body(const LstmBwdArgsB& a, const int t
                 }
             }
         }
-        const bf16_t* brow = dpl - 4 * S * RS + (q * 16 + j) * RS;      // the whole image (PF == 1: rows of the chunk's other steps too)
+        const bf16_t* brow = dpl + (q * 16 + j) * RS;
         f32x4 acc0 = zero4, acc1 = zero4;
 #pragma unroll
         for (int s = 0; s < KS; s += 2) {
@@ -302,47 +184,24 @@ __device__ __forceinline__ void lstm_bwd_body(const LstmBwdArgsB& a, const int t
             acc0 = mfma_bf16_16x16x32(whT[s], bv0, acc0);
             acc1 = mfma_bf16_16x16x32(whT[s + 1], bv1, acc1);
         }
-        if constexpr (PF == 1) {                           // behind the recurrent MFMAs' issue, in front of the wait for their result
-            if constexpr (S == 0) {                        // the dx tile of chunk c + 1 is complete (same order and mask indexing as dx_gemm)
-                const int c1 = (t >> 2) + 1;
-                const f32x4 d = dxa0 + dxa1;               // unmasked: the layer below re-applies the inter-layer dropout mask at use
-                if (c1 < NC)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, d), dx_rsrc, (uint32_t)((c1 * NW + ht) * 64 + lane) * 16, 0, 16);
-            }
-        }
         // accumulator lanes (q, j<4, r) -> cell lanes (q, jj): register jj>>2 of lane jj&3, by DPP (see lstm_fwd_bf16.hip)
-        dh_rec = redeal1s<S>(acc0 + acc1);
+        dh_rec = redeal1(acc0 + acc1);
     };
 
     __syncthreads();                                       // images zeroed, wo_lds visible
     Prefetch P0, P1, P2, P3;
     if (a.dh_last) dh_rec = vmask * a.dh_last[(size_t)bc * H + cu];    // gradient on h_{T-1}
     int t = T - 1;
-    for (int k = T & 3; k > 0; --k, --t) { fetch(P0, t); step(IntC<0>{}, P0, t); }     // peel so that the main loop runs whole quadruples (PF: T % 4 == 0)
+    for (int k = T & 3; k > 0; --k, --t) { fetch(P0, t); step(P0, t); }     // peel so that the main loop runs whole quadruples
     fetch(P0, t); fetch(P1, t - 1); fetch(P2, t - 2); fetch(P3, t - 3);
     // Drain once here: the waits inside the loop are static, so anything still in flight from the prologue (weights,
     // peeled steps, these first fetches) would otherwise force a vmcnt(0) into every iteration.
     __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0) only
     for (; t >= 3; t -= 4) {
-        step(IntC<PF == 1 ? 3 : 0>{}, P0, t);
-        step(IntC<PF == 1 ? 2 : 0>{}, P1, t - 1);
-        step(IntC<PF == 1 ? 1 : 0>{}, P2, t - 2);
-        step(IntC<0>{}, P3, t - 3);
-    }
-    if constexpr (PF == 1) {                               // chunk 0's dx (its image is buffer 0), then everything is in memory
-        const bf16_t* xrow = dp_lds + (q * 16 + j) * RS;
-        dxa0 = zero4; dxa1 = zero4;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 bv = *reinterpret_cast<const bf16x8*>(xrow + 8 * ks);
-            if (ks & 1) dxa1 = mfma_bf16_16x16x32(wx_frag(ks), bv, dxa1);
-            else dxa0 = mfma_bf16_16x16x32(wx_frag(ks), bv, dxa0);
-        }
-        const f32x4 d = dxa0 + dxa1;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, d), dx_rsrc, (uint32_t)(ht * 64 + lane) * 16, 0, 16);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(flag_out, (unsigned)NC, SHM_RLX_AGENT);
+        step(P0, t);
+        step(P1, t - 1);
+        step(P2, t - 2);
+        step(P3, t - 3);
     }
     if constexpr (PRODUCE) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -400,12 +259,13 @@ __device__ __forceinline__ void lstm_bwd_fused_dx_body(const LstmBwdArgsB& a, co
     // ---- the upper layer's dpre rows: sc1 loads behind the producer's progress word
     const __amdgpu_buffer_rsrc_t up_rsrc = make_rsrc(up.dpre_seq + (size_t)tile * T * WPT * 4 * H, (uint32_t)T * WPT * 4 * H * 2);
     int avail = 0;                                         // wave-uniform: the producer's steps >= T - avail are in memory
+    const uint64_t flag_in_s = uniform_addr((const void*)flag_in);
     auto wait_for = [&](int need) {
         if (avail >= need) return;
         unsigned v, spins = 0;
 #pragma clang loop unroll(disable)
         for (;;) {
-            v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flag_in, SHM_RLX_AGENT));
+            v = poll_uniform(flag_in_s);                      // scalar load: no vmcnt drain (common.hpp)
             if ((int)v >= need) break;
             if (++spins > SPIN_MAX) {                      // give up: finish with garbage, flagged in the err word
                 if (lane == 0) __hip_atomic_store(err, 0x80000001u + (unsigned)tile, SHM_RLX_AGENT);
@@ -567,32 +427,6 @@ __global__ void __launch_bounds__(4 * H) lstm_bwd_pair_bf16_kernel(LstmBwdPairAr
     else lstm_bwd_fused_dx_body<H, DROP>(p.l0, p.l1, tile, sync + 16 * (1 + tile), (gu32*)p.err);
 }
 
-// Second form (T % 4 == 0): the top layer forms dx out of its own operand images (lstm_bwd_body, PF == 1) and the layer below is the plain
-// DH == 1 recurrence behind the progress word (PF == 2).  The first form's layer-0 role carried W_hh^T, W_ih^T, eight record slots and the
-// staged rows in 256 VGPRs; with nothing left to hold operand fragments in flight its recurrent MFMAs waited for one LDS read pair at a
-// time (0.85 us per step against 0.6 us for the plain recurrence).  Same sync block, ticket deal and results as the first form.
-template <int H, int DHTOP, bool DROP>
-__global__ void __launch_bounds__(4 * H) lstm_bwd_pair2_bf16_kernel(LstmBwdPairArgsB p) {
-    extern __shared__ __attribute__((aligned(16))) bf16_t smem_b[];
-    gu32* sync = (gu32*)p.sync;
-    const int tiles = gridDim.x >> 1;
-    int* role_lds = reinterpret_cast<int*>(reinterpret_cast<char*>(smem_b) + p.role_lds_off);
-    if (threadIdx.x == 0) *role_lds = (int)__hip_atomic_fetch_add(sync, 1u, SHM_RLX_AGENT);
-    __syncthreads();
-    const int ticket = *role_lds;
-    __syncthreads();
-    const int grp = ticket / (2 * PAIR_GROUP), r = ticket - grp * 2 * PAIR_GROUP, base = grp * PAIR_GROUP;
-    const int ntg = min(PAIR_GROUP, tiles - base);
-    const bool producer = r < ntg;
-    const int tile = base + (producer ? r : r - ntg);
-    if (threadIdx.x == 0 && producer) {                   // nobody touches the other block in this launch
-        p.sync_other[16 * (1 + tile)] = 0u;
-        if (ticket == 0) p.sync_other[0] = 0u;
-    }
-    if (producer) lstm_bwd_body<H, DHTOP, false, 1, false>(p.l1, tile, sync + 16 * (1 + tile), (gu32*)p.err);
-    else lstm_bwd_body<H, 1, false, 2, DROP>(p.l0, tile, sync + 16 * (1 + tile), (gu32*)p.err);
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
 // dx[r][k] = sum_m dpre[r][m] W_ih[m][k]  for all r = (window, step) at once — the time-parallel half of BPTT.
 // Workgroup = 8 (H/16) waves; wave w owns output columns [16w, 16w+16) with its W_ih^T fragments in registers and walks
@@ -704,28 +538,6 @@ int launch_pair(const LstmBwdPairArgsB& p0, hipStream_t s) {
     p.role_lds_off = (int)lds;
     const bool drop = t.drop_p > 0.f;
     void (*kern)(LstmBwdPairArgsB);
-    static const bool form1 = [] { const char* e = getenv("SHM_BWD_PAIR_FORM1"); return e && e[0] == '1'; }();     // A/B knob: dx formed by layer 0
-    // top role of the second form: images + re-deal scratch + W_out + the LDS part of W_ih^T (H = 128: 14 of 16 k-steps)
-    const size_t lds2 = 2 * img + sizeof(float) * ((H / 16) * 64 + (t.dy ? t.Dy * H : 0)) + (H == 128 ? (size_t)(H / 8 - 2) * (H / 16) * 64 * 16 : 0);
-    if (t.T % 4 == 0 && !form1 && lds2 + 32 <= 160 * 1024) {
-        SHM_REQUIRE(t.dx_seq && b.dh_seq == t.dx_seq, SHM_EINVAL, "lstm_bwd_pair: the dx buffer of the two layers must be one");
-        p.l0.drop_p = t.drop_p; p.l0.drop_seed = t.drop_seed; p.l0.drop_stack = t.drop_stack;      // the mask on dx is applied by the layer below
-        SHM_REQUIRE((int64_t)(t.T / 4) * (H / 16) * 64 * 16 < ((int64_t)1 << 31), SHM_EINVAL, "lstm_bwd_pair: T too long for 32-bit buffer offsets");
-        p.role_lds_off = (int)((lds2 + 15) & ~(size_t)15);
-        static const void* raised[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-        if (t.dy) kern = t.Dy == 4 ? (drop ? lstm_bwd_pair2_bf16_kernel<H, 2, true> : lstm_bwd_pair2_bf16_kernel<H, 2, false>)
-                                   : (drop ? lstm_bwd_pair2_bf16_kernel<H, 3, true> : lstm_bwd_pair2_bf16_kernel<H, 3, false>);
-        else kern = drop ? lstm_bwd_pair2_bf16_kernel<H, 0, true> : lstm_bwd_pair2_bf16_kernel<H, 0, false>;
-        bool done = false;
-        for (const void* k : raised) done = done || k == (const void*)kern;
-        if (!done) {
-            SHM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, p.role_lds_off + 16));
-            for (auto& k : raised) if (!k) { k = (const void*)kern; break; }
-        }
-        SHM_LAUNCH(kern, dim3(2 * tiles), dim3(4 * H), (size_t)p.role_lds_off + 16, s, p);
-        SHM_LAUNCH_CHECK();
-        return SHM_OK;
-    }
     if (t.dy) kern = t.Dy == 4 ? (drop ? lstm_bwd_pair_bf16_kernel<H, 2, true> : lstm_bwd_pair_bf16_kernel<H, 2, false>)
                                : (drop ? lstm_bwd_pair_bf16_kernel<H, 3, true> : lstm_bwd_pair_bf16_kernel<H, 3, false>);
     else kern = drop ? lstm_bwd_pair_bf16_kernel<H, 0, true> : lstm_bwd_pair_bf16_kernel<H, 0, false>;

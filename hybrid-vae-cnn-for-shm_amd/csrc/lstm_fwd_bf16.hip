@@ -129,12 +129,13 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int t
     const __amdgpu_buffer_rsrc_t in_rsrc = make_rsrc(CONSUME ? reinterpret_cast<const bf16_t*>(a.in) + (size_t)tile * T * WPT * H : nullptr, CONSUME ? seq_bytes : 0);
     const __amdgpu_buffer_rsrc_t out_rsrc = make_rsrc(PRODUCE ? a.h_seq + (size_t)tile * T * WPT * H : nullptr, PRODUCE ? seq_bytes : 0);
     int avail = 0;                                        // wave-uniform: producer steps < avail are in memory
+    const uint64_t flag_in_s = uniform_addr((const void*)flag_in);
     auto wait_for = [&](int need) {
         if (avail >= need) return;
         unsigned v, spins = 0;
 #pragma clang loop unroll(disable)
         for (;;) {
-            v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flag_in, SHM_RLX_AGENT));
+            v = poll_uniform(flag_in_s);                      // scalar load: no vmcnt drain (common.hpp)
             if ((int)v >= need) break;
             if (++spins > SPIN_MAX) {                      // give up: finish with garbage, flagged in the err word
                 if (lane == 0) __hip_atomic_store(err, 1u + (unsigned)tile, SHM_RLX_AGENT);

@@ -441,12 +441,13 @@ __device__ __forceinline__ void lstm_fwd_sp_fused(const LstmFwdArgsS& a, const i
     const uint32_t thr = drop_threshold(a.drop_p);
     const float dscale = DROP ? 1.0f / (1.0f - a.drop_p) : 1.0f;
     int avail = 0;                                     // wave-uniform: producer steps < avail are in memory
+    const uint64_t flag_in_s = uniform_addr((const void*)flag_in);
     auto wait_for = [&](int need) {
         if (avail >= need) return;
         unsigned v, spins = 0;
 #pragma clang loop unroll(disable)
         for (;;) {
-            v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flag_in, SHM_RLX_AGENT));
+            v = poll_uniform(flag_in_s);                      // scalar load: no vmcnt drain (common.hpp)
             if ((int)v >= need) break;
             if (++spins > SPIN_MAX) {                  // give up: finish with garbage, flagged in the err word
                 if (lane == 0) __hip_atomic_store(err, 1u + (unsigned)tile, SHM_RLX_AGENT);
@@ -863,12 +864,13 @@ __device__ __forceinline__ void dx_sp_follow(const DxArgsS& a, const int tile, c
     const __amdgpu_buffer_rsrc_t in_hi = make_rsrc(a.dpre_hi + (size_t)tile * T * WPT * 4 * H, seq_bytes);
     const __amdgpu_buffer_rsrc_t in_lo = make_rsrc(a.dpre_lo + (size_t)tile * T * WPT * 4 * H, seq_bytes);
     int avail = 0;                                         // wave-uniform: the producer's steps >= T - avail are in memory
+    const uint64_t flag_in_s = uniform_addr((const void*)flag_in);
     auto wait_for = [&](int need) {
         if (avail >= need) return;
         unsigned v, spins = 0;
 #pragma clang loop unroll(disable)
         for (;;) {
-            v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flag_in, SHM_RLX_AGENT));
+            v = poll_uniform(flag_in_s);                      // scalar load: no vmcnt drain (common.hpp)
             if ((int)v >= need) break;
             if (++spins > SPIN_MAX) {
                 if (lane == 0) __hip_atomic_store(err, 0x40000001u + (unsigned)tile, SHM_RLX_AGENT);
