@@ -128,6 +128,13 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int t
     const uint32_t seq_bytes = (uint32_t)T * WPT * H * 2;
     const __amdgpu_buffer_rsrc_t in_rsrc = make_rsrc(CONSUME ? reinterpret_cast<const bf16_t*>(a.in) + (size_t)tile * T * WPT * H : nullptr, CONSUME ? seq_bytes : 0);
     const __amdgpu_buffer_rsrc_t out_rsrc = make_rsrc(PRODUCE ? a.h_seq + (size_t)tile * T * WPT * H : nullptr, PRODUCE ? seq_bytes : 0);
+    // Stores that a step issues for ANOTHER step (the record of step t - 1, the masked input of step t + 5) go through descriptors of the
+    // tile's block: for a step outside [0, T) the hardware drops them (range check), so the time loop needs no branch around them — a
+    // branch ends the basic block, and the scheduler can then not place this vector work between the recurrent MFMAs.
+    const __amdgpu_buffer_rsrc_t xd_rsrc = make_rsrc((DROP && !XF32 && !CONSTIN) ? a.xdrop + (size_t)tile * T * WPT * H : nullptr,
+                                                     (DROP && !XF32 && !CONSTIN) ? seq_bytes : 0);
+    const __amdgpu_buffer_rsrc_t rec_rsrc = make_rsrc(SAVE ? reinterpret_cast<const char*>(a.sv_g) + (size_t)tile * T * NW * 64 * 12 : nullptr,
+                                                      SAVE ? (uint32_t)T * NW * 64 * 12 : 0);
     int avail = 0;                                        // wave-uniform: producer steps < avail are in memory
     const uint64_t flag_in_s = uniform_addr((const void*)flag_in);
     auto wait_for = [&](int need) {
@@ -176,7 +183,7 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int t
             }
             const bf16_t v = (bf16_t)f;
             // keep the masked input for the dW_ih GEMM (same tile-blocked layout as the source)
-            if (DROP) a.xdrop[((size_t)tile * T + t) * WPT * H + tid] = v;
+            if (DROP) __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, v), xd_rsrc, (uint32_t)(t * WPT * H + tid) * 2, 0, 0);
             xl[e_img_off] = v;
         }
     };
@@ -296,14 +303,15 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int t
         // in order, so vector work placed behind the MFMA block would wait for the matrix pipe, and placed in front of the
         // barrier (where it used to be) it delayed every wave's arrival.
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);                     // the recurrent MFMAs are the critical path of both waves of a SIMD
         mma_h(acc, h_lds + cur * HBUF);
-        __builtin_amdgcn_s_setprio(0);
-        if constexpr (SAVE) {
-            if (t > 0) sv[(size_t)(t - 1) * NW * 64] = rec_prev;
+        if constexpr (SAVE) {                              // record of step t - 1 (t == 0: out of range, dropped)
+            typedef unsigned u32v3 __attribute__((ext_vector_type(3)));
+            const u32v3 r3 = {rec_prev[0], rec_prev[1], rec_prev[2]};
+            __builtin_amdgcn_raw_buffer_store_b96(r3, rec_rsrc, (uint32_t)(((t - 1) * NW + ht) * 64 + lane) * 12, 0, 0);
         }
         if constexpr (GRP) {                               // x_{4G+7} must be in the image before step 4G+3 forms group G+1's projection
-            if (t + 5 < T) x_commit(X, t + 5, 0);
+            if constexpr (XF32) { if (t + 5 < T) x_commit(X, t + 5, 0); }
+            else x_commit(X, t + 5, 0);                    // steps >= T: rows nobody reads, stores out of range (dropped)
             x_fetch(X, t + 9);
         } else if constexpr (!CONSTIN) {
             if (t + 2 < T) x_commit(X, t + 2, cur);
@@ -458,6 +466,7 @@ int launch_x(const LstmFwdArgsB& a, hipStream_t s) {
     const int tiles = ceil_div(a.B, WPT);
     const size_t lds = sizeof(bf16_t) * 4 * 16 * (4 * lds_row_stride(H / 4) + 2 * lds_row_stride(XK * 8)) + sizeof(float) * (H / 16) * 256;   // four h images (GRP), two x images
     const bool drop = a.drop_p > 0.f && !XF32 && !CONSTIN, save = a.sv_g != nullptr;
+    SHM_REQUIRE((int64_t)a.T * (H / 16) * 64 * 12 < ((int64_t)1 << 31), SHM_EINVAL, "lstm_fwd_bf16: T too long for 32-bit buffer offsets");
     void (*kern)(LstmFwdArgsB);
     if constexpr (XF32 || CONSTIN)
         kern = save ? lstm_fwd_bf16_kernel<H, XK, XF32, false, CONSTIN, true> : lstm_fwd_bf16_kernel<H, XK, XF32, false, CONSTIN, false>;
