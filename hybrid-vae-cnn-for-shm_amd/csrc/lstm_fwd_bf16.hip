@@ -294,7 +294,6 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int t
         constexpr int S = decltype(sc)::value;
         const int cur = GRP ? S : t & 1;                   // GRP: image S holds h_{t-1} in rows 4S.., image (S+1)&3 receives h_t
         constexpr int NXT = (S + 1) & 3;
-        if (t > 0) h_flush(t - 1, cur);                    // h_{t-1} sits complete in h_lds[cur]
         f32x4 acc[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g] = xproj[g];
@@ -323,6 +322,9 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgsB& a, const int t
             __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);     // ... two vector instructions
         }
         __builtin_amdgcn_sched_barrier(0);
+        // h_{t-1} sits complete in h_lds[cur] until the end of the next step: copied out BEHIND the MFMA issue (in front of it, the copying
+        // wave started its matrix work an LDS round trip late at every step and the other seven waited for it at the barrier)
+        if (t > 0) h_flush(t - 1, cur);
 
         float gate[4];
         redeal(sc, acc, gate);
