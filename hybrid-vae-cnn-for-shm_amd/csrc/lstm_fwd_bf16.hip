@@ -17,11 +17,18 @@
 //     copied out of the completed image one step later as 16-byte coalesced stores;
 //   * the layer input of a bf16 layer is staged ONE ELEMENT PER THREAD (4H inputs per step = 4H threads; dropout mask by the
 //     counter hash of that element) — staging 16-byte pieces in wave 0 made that wave the straggler of every barrier;
-//     x_{t+2..t+4} are prefetched in three rotating register slots; the time loop is branch-free (clamped loads, T % 3
-//     steps peeled, slot use pinned with an empty asm) so the compiler emits one counted s_waitcnt vmcnt per step;
-//   * the input projection W_ih x_{t+1} is formed during step t, its MFMAs hand-interleaved with the cell update's vector
-//     instructions (sched_barrier-pinned): it does not depend on h_t, and both waves of a SIMD are in phase, so without the
-//     interleave the matrix pipe idles through every cell update.
+//   * (r3) the input projection of a layer with a time-varying input is formed FOUR STEPS PER MFMA TILE: the 16 columns of the B
+//     operand are 4 steps x 4 windows (row 4s + w of a group's x image), so a group of four steps costs 4 x XK input MFMAs instead
+//     of 16 x XK (measured: every MFMA per step costs ~2 us of a 256-step launch, hidden or not).  The recurrent product then has to
+//     land in columns 4s..4s+3 at step s = t & 3: the h image of step t keeps its windows in rows 4s..4s+3 (one image per s, the
+//     other rows stay zero) and the re-deal takes its source lanes from that column group.  Per output element the MFMA sequence is
+//     what it was (bias, W_ih k-steps, W_hh k-steps): bit-identical results.  The group's MFMAs are issued in its last step,
+//     hand-interleaved with the cell update's vector instructions (sched_barrier-pinned); x_{t+5} is committed and x_{t+9}
+//     requested at step t (four rotating register slots, loop unrolled by four, counted s_waitcnt vmcnt);
+//   * (r3) everything a step does for ANOTHER step (record of t-1, masked input of t+5) is stored through range-checked buffer
+//     descriptors, so the time loop has no branch around it and the scheduler places that vector work BETWEEN the recurrent MFMAs
+//     (a wave issues in order: behind the block it waits for the matrix pipe); h_{t-1} is copied out behind the MFMA issue, not
+//     in front of it (the copying wave used to start its matrix work an LDS round trip late, at every step).
 // Ablation of one layer-1 step (round 1): recurrent MFMAs 21 %, input MFMAs 10 %, accumulator re-deal through LDS 16 %
 // (-> DPP), input staging + dropout hashing in wave 0 9 % (-> per thread), cell update + barrier + LDS operand round trip 45 %.
 //

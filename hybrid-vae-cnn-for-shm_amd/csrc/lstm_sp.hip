@@ -25,6 +25,9 @@
 //     layer below is the time-parallel dx_sp_kernel, weight gradients are gemm_tn_bf16.hip run over three plane pairs.
 #include <type_traits>
 #include "kernels.hpp"
+#ifndef SHM_SP_COPY_AT
+#define SHM_SP_COPY_AT (KS / 2)
+#endif
 
 namespace shm {
 
@@ -784,22 +787,30 @@ __device__ __forceinline__ void lstm_bwd_sp_body(const LstmBwdArgsS& a, const in
         if constexpr (PRODUCE) {
             // every storing wave has, in step t + 1, waited until its dpre store of step t + DLY had retired
             if (tid == 0 && t + DLY <= T - 1) __hip_atomic_store(flag_out, (unsigned)(T - (t + DLY)), SHM_RLX_AGENT);
+        }
+        const bf16_t* brow = dpl + (q * 16 + j) * RS;
+        f32x4 acc0 = zero4, acc1 = zero4;
+        auto mma_range = [&](int s0, int s1) {
+#pragma unroll
+            for (int s = s0; s < s1; s += 2) {
+                const bf16x8 bv0 = *reinterpret_cast<const bf16x8*>(brow + 8 * s);
+                const bf16x8 bv1 = *reinterpret_cast<const bf16x8*>(brow + 8 * s + 8);
+                acc0 = mfma_bf16_16x16x32(whi[s], bv0, acc0);
+                acc1 = mfma_bf16_16x16x32(whi[s + 1], bv1, acc1);
+                acc0 = mfma_bf16_16x16x32(wlo[s], bv0, acc0);
+                acc1 = mfma_bf16_16x16x32(wlo[s + 1], bv1, acc1);
+            }
+        };
+        mma_range(0, SHM_SP_COPY_AT);
+        // dpre_t -> HBM out of the complete image, every thread one 16-byte chunk: placed inside the MFMA block (in front of it every wave
+        // started its matrix work an LDS round trip late)
+        if constexpr (PRODUCE) {
             const u32x4 v = *reinterpret_cast<const u32x4*>(dpl + f_img_off);
             __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, (uint32_t)(t * WPT * 4 * H + fcch * 8) * 2, 0, 16);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DLY - 1) * OPS) : "memory");   // retires the store of step t + DLY - 1
         } else
             *reinterpret_cast<bf16x8*>(f_dst + (size_t)t * WPT * 4 * H) = *reinterpret_cast<const bf16x8*>(dpl + f_img_off);
-        const bf16_t* brow = dpl + (q * 16 + j) * RS;
-        f32x4 acc0 = zero4, acc1 = zero4;
-#pragma unroll
-        for (int s = 0; s < KS; s += 2) {
-            const bf16x8 bv0 = *reinterpret_cast<const bf16x8*>(brow + 8 * s);
-            const bf16x8 bv1 = *reinterpret_cast<const bf16x8*>(brow + 8 * s + 8);
-            acc0 = mfma_bf16_16x16x32(whi[s], bv0, acc0);
-            acc1 = mfma_bf16_16x16x32(whi[s + 1], bv1, acc1);
-            acc0 = mfma_bf16_16x16x32(wlo[s], bv0, acc0);
-            acc1 = mfma_bf16_16x16x32(wlo[s + 1], bv1, acc1);
-        }
+        mma_range(SHM_SP_COPY_AT, KS);
         dh_rec = redeal_hl(acc0 + acc1);
     };
 
