@@ -1,7 +1,7 @@
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_gpu_vae_bf16.py tests/test_gpu_split_pair.py tests/test_gpu_fullsize_parity.py tests/test_gpu_vae.py -x -q 2>&1 | tail -3 > gpurun_out/r3_poll_tests.log; rc=$?; cat gpurun_out/r3_poll_tests.log; [ $rc = 0 ] || exit 1
-for P in split; do
+timeout -k 10 900 python -m pytest tests/test_gpu_vae_bf16.py tests/test_gpu_split_pair.py tests/test_gpu_fullsize_parity.py tests/test_gpu_vae.py tests/test_gpu_multirank.py tests/test_gpu_c_abi.py -x -q 2>&1 | tail -3 > gpurun_out/r3_poll_tests.log; rc=$?; cat gpurun_out/r3_poll_tests.log; [ $rc = 0 ] || exit 1
+for P in bf16; do
 B="python bench.py --precision $P --steps 100 --warmup 10 --no-cpu-baseline --no-fp32-leg --no-cnn-leg --no-inference-leg --no-parity-leg"
 for i in 1 2; do
 for v in prev new; do
