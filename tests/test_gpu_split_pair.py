@@ -1,5 +1,5 @@
 """Split-precision path, layer-pipelined forward (round 3): lstm_fwd_pair_sp_kernel runs both layers of a stack in ONE launch and
-forms layer 1's input projection inside the recurrent workgroup (W_ih hi in LDS, W_ih lo streamed from L2, four steps per MFMA tile).
+forms layer 1's input projection inside the recurrent workgroup (W_ih as fp16 in LDS + an fp8 residual in registers, four steps per MFMA tile).
 Its MFMA sequence per output element is the one of the two-launch form (xproj_sp_kernel + lstm_fwd_sp_kernel), so every result must be
 BIT-IDENTICAL to one launch per layer — which is itself pinned to the reference goldens at 1e-4 (tests/test_gpu_vae.py, split legs).
 Reference arithmetic: 4DOF/Scripts/Models/temporal_vae.py:51-77 (nn.LSTM stacks), 4DOF/Scripts/03_train_vae.py:260-271 (train step)."""
