@@ -1,4 +1,4 @@
-"""One-off extended stress of the split path's in-launch hand-offs (forward pair, top-layer backward + dx) under uneven background load:
+"""One-off extended stress of the in-launch hand-offs of the split (default) or bf16 path (forward pair, top-layer backward + dx) under uneven background load:
 N repetitions of a pipelined train step at three shapes while a second stream streams copies of varying size through HBM / L2, each
 compared BIT FOR BIT with the one-launch-per-layer result.  (The GPU suite runs 10 repetitions of one shape; this is the long version.)"""
 import sys
@@ -12,6 +12,7 @@ from shm_hip._capi import lib
 from shm_hip.trainer import VAETrainer
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+PREC = sys.argv[2] if len(sys.argv) > 2 else "split"          # "bf16": the same stress of the bf16 pair launches
 side = torch.cuda.Stream()
 a = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device="cuda")
 b = torch.empty_like(a)
@@ -25,7 +26,7 @@ for (B, T, H) in ((512, 256, 128), (300, 64, 128), (128, 100, 64)):
         lib.shm_set_pair_launch(on)
         try:
             torch.manual_seed(21)
-            m = TemporalVAE(4, 16, H, 2, 0.3, precision="split").cuda().train()
+            m = TemporalVAE(4, 16, H, 2, 0.3, precision=PREC).cuda().train()
             tr = VAETrainer(m, lr=1e-3, weight_decay=1e-5, max_norm=2.0)
             st = tr.step(x, 0.3, eps=eps, drop_seed=5).clone()
             tr.engine.check_status()
