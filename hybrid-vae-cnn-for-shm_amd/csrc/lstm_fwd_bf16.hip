@@ -511,7 +511,8 @@ int launch_pair_h(const LstmFwdPairArgsB& p0, hipStream_t s) {
     SHM_REQUIRE(b.in == (const void*)a.h_seq && !b.in_f32 && !b.in_const && b.In == H, SHM_EINVAL, "lstm_fwd_pair: layer 1 must read layer 0's h_seq");
     SHM_REQUIRE(a.B == b.B && a.T == b.T, SHM_EINVAL, "lstm_fwd_pair: shape mismatch");
     SHM_REQUIRE((a.sv_g != nullptr) == (b.sv_g != nullptr), SHM_EINVAL, "lstm_fwd_pair: both layers save or neither");
-    SHM_REQUIRE((int64_t)a.T * WPT * H * 2 < ((int64_t)1 << 31), SHM_EINVAL, "lstm_fwd_pair: T too long for 32-bit buffer offsets");
+    SHM_REQUIRE((int64_t)a.T * WPT * H * 2 < ((int64_t)1 << 31) && (int64_t)a.T * (H / 16) * 64 * 12 < ((int64_t)1 << 31), SHM_EINVAL,
+                "lstm_fwd_pair: T too long for 32-bit buffer offsets");
     const bool xf32 = a.in_f32 && !a.in_const;
     if (xf32) SHM_REQUIRE(a.In <= 16, SHM_EINVAL, "lstm_fwd_pair: fp32 input width %d too wide (<= 16)", a.In);
     else SHM_REQUIRE(a.in_const && a.In == H, SHM_EINVAL, "lstm_fwd_pair: layer 0 must be the fp32 input or the constant-input layer");
