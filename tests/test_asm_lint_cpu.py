@@ -26,3 +26,25 @@ def test_no_read_of_a_pending_handoff_load(tmp_path):
     r = subprocess.run([sys.executable, str(ROOT / "tools" / "lint_pending_loads.py"), str(out)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
     assert "0 problems" in r.stdout, r.stdout[-500:]
+
+
+@pytest.mark.parametrize("src", ["lstm_fwd_bf16.hip", "lstm_bwd_bf16.hip", "lstm_sp.hip"])
+def test_progress_word_polls_use_a_clean_scalar_address(tmp_path, src):
+    """The pair launches poll their progress word with `s_load_dword ... glc` from an SGPR pair built by two `v_readfirstlane`s
+    (csrc/common.hpp: uniform_addr / poll_uniform).  The builtin returns int: widened without a cast, a low half with bit 31 set
+    sign-extends into the high half (the compiler's `s_bfe_i64`), the poll reads a wild address and the kernel faults — on some
+    allocations only.  Every pair kernel must contain the polls and none of that widening."""
+    hipcc = Path("/opt/rocm/bin/hipcc")
+    if not hipcc.exists():
+        pytest.skip("no hipcc")
+    flags = None
+    for line in (CSRC / "Makefile").read_text().splitlines():
+        if line.startswith("CXXFLAGS"):
+            flags = line.split("=", 1)[1].replace("$(ARCH)", "gfx950").split()
+    assert flags, "CXXFLAGS not found in the Makefile"
+    out = tmp_path / (src + ".s")
+    subprocess.run([str(hipcc), *flags, "-S", "--cuda-device-only", str(CSRC / src), "-o", str(out)], check=True, cwd=CSRC)
+    asm = out.read_text()
+    polls = [i for i, l in enumerate(asm.splitlines()) if "s_load_dword " in l and l.rstrip().endswith("glc")]
+    assert polls, "no scalar poll found in " + src
+    assert "s_bfe_i64" not in asm, "a 64-bit sign extension in " + src + ": check uniform_addr()"
