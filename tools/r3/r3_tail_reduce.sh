@@ -8,7 +8,7 @@ SHM_BWD_TAIL_REDUCE=$v timeout -k 10 300 $B > gpurun_out/r3_tr_${v}_$i.json 2> g
 import json
 j=json.load(open("gpurun_out/r3_tr_${v}_$i.json"))
 k=j["roofline"]["kernels_ms"]
-print("tail=$v", j["value"], j["ms_per_step"], {a:k[a] for a in ("lstm_bwd.dec","lstm_bwd.enc","dw_gemm.dec0","dw_gemm.enc0")})
+print("tail=$v", j["value"], j["ms_per_step"], {a:k[a] for a in ("lstm_bwd.dec","lstm_bwd.enc","dw_gemm.dec0","dw_gemm.out")})
 PY
 done
 done
