@@ -67,8 +67,6 @@ struct shm_vae_plan {
     size_t recon, score, d_recon, d_mu, d_lv, dpre_seq, dx_seq, dpre_tsum, gemm_partial, colsum_scratch;
     size_t gemm_partial_b, gemm_partial_c;   // bf16 pair path: split-K scratch of the layer-0 GEMM / the fp32 dec0 dW_ih GEMM (all reduced in one batch)
     size_t dpre_seq2, dpre_tsum2;   // bf16 path, 2 layers: the top layer's dpre / sum_t dpre (both layers' live at once in a pair launch)
-    size_t dpre_tsum_e, dpre_tsum2_e;   // ... and the ENCODER stack's own sum_t dpre pair: the decoder stack's bias reductions read theirs while the
-                                    // encoder stack's pair launch is running (they ride in its tail)
     size_t gemm_partial_elems;
     size_t narrow_scratch;  // block partials of narrow_tn (enc0 dW_ih)
     size_t narrow_scratch2; // block partials of narrow_tn (dW_out): both may be pending in one reduce batch
@@ -307,10 +305,7 @@ extern "C" int shm_vae_plan_create(const shm_vae_config* cfg, int32_t B, int32_t
                 p->dpre_set_tsum[k] = k == 0 ? p->dpre_tsum : take((size_t)B * 4 * H);
             }
         }
-        if (bf && !sp && L == 2) {
-            p->dpre_seq2 = take_bytes(2 * Rq * 4 * H); p->dpre_tsum2 = take((size_t)B * 4 * H);
-            p->dpre_tsum_e = take((size_t)B * 4 * H); p->dpre_tsum2_e = take((size_t)B * 4 * H);
-        }
+        if (bf && !sp && L == 2) { p->dpre_seq2 = take_bytes(2 * Rq * 4 * H); p->dpre_tsum2 = take((size_t)B * 4 * H); }
         size_t gp = 0;
         auto upd = [&](int R, int M, int N) { const size_t e = gemm_tn_partial_elems(R, M, N); if (e > gp) gp = e; };
         upd((int)BT, H, D); upd((int)BT, 4 * H, H); upd((int)BT, 4 * H, D); upd(B, 4 * H, H); upd(B, H, Z); upd(B, Z, H);
@@ -897,11 +892,6 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
     const bool pair_bwd = bf && !sp && L == 2 && pair_launch_enabled();
     ReduceJobs rjobs;                    // pair path: every reduction of a stack in ONE launch at the end of the stack
     rjobs.n = 0;
-    // ... and at H = 128 the decoder stack's batch does not get a launch: it rides in the tail of the encoder stack's pair launch, whose
-    // top-layer workgroups are idle for the last quarter of it (SHM_BWD_TAIL_REDUCE=0: its own launch, as before)
-    ReduceJobs pending;
-    pending.n = 0;
-    static const bool tail_reduce = [] { const char* e = getenv("SHM_BWD_TAIL_REDUCE"); return !(e && e[0] == '0'); }();
     {
         KernelTimer kt("dw_gemm.out", gs);
         if ((rc = launch_narrow_tn(h_top, bf ? 1 : 0, H, H, d_recon, D, bf ? ceil_div(B, SHM_WPT) * SHM_WPT * T : BT, grads + p->out_w, 0, grads + p->out_b,
@@ -1139,20 +1129,13 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
         if (bf && L == 2 && pair_launch_enabled()) {
             // both layers in one launch (layer 0 forms dx itself, a few steps behind layer 1); layer 0 keeps the primary
             // dpre / tsum buffers because the head reads decoder layer 0's sum_t dpre
-            bf16_t* dps1 = at<bf16_t>(ws, p->dpre_seq2);
-            float* tsum1 = at<float>(ws, stack == 0 ? p->dpre_tsum2_e : p->dpre_tsum2);
-            float* tsum0 = stack == 0 ? at<float>(ws, p->dpre_tsum_e) : dpre_tsum;      // (the head reads the decoder's layer-0 sums)
+            bf16_t* dps1 = at<bf16_t>(ws, p->dpre_seq2); float* tsum1 = at<float>(ws, p->dpre_tsum2);
             LstmBwdPairArgsB pa;
-            pa.l1 = bwd_args_bf(1, dps1, tsum1); pa.l0 = bwd_args_bf(0, at<bf16_t>(ws, p->dpre_seq), tsum0);
+            pa.l1 = bwd_args_bf(1, dps1, tsum1); pa.l0 = bwd_args_bf(0, at<bf16_t>(ws, p->dpre_seq), dpre_tsum);
             pa.sync = at<unsigned>(ws, p->pair_sync + (size_t)p->sync_next * lstm_fwd_pair_sync_bytes(B));
             pa.sync_other = at<unsigned>(ws, p->pair_sync + (size_t)(p->sync_next ^ 1) * lstm_fwd_pair_sync_bytes(B));
             p->sync_next ^= 1;
             pa.err = at<unsigned>(ws, p->misc); pa.role_lds_off = 0;
-            pa.tail.n = 0; pa.tail_blocks = 0;
-            if (pending.n > 0) {                           // the previous stack's reductions: in this launch's tail
-                pa.tail = pending; pa.tail_blocks = reduce_jobs_finalize(pa.tail);
-                pending.n = 0;
-            }
             int r;
             {
                 KernelTimer kt(stack == 0 ? "lstm_bwd.enc" : "lstm_bwd.dec", s);
@@ -1164,8 +1147,7 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
                 if ((r = layer_grads_bf(1, dps1, tsum1, &rjobs))) return r;
             }
             KernelTimer kt(stack == 0 ? "dw_gemm.enc0" : "dw_gemm.dec0", s);
-            if ((r = layer_grads_bf(0, at<char>(ws, p->dpre_seq), tsum0, &rjobs))) return r;
-            if (stack == 1 && H == 128 && tail_reduce) { pending = rjobs; rjobs.n = 0; return SHM_OK; }   // the encoder stack's pair launch takes it
+            if ((r = layer_grads_bf(0, at<char>(ws, p->dpre_seq), dpre_tsum, &rjobs))) return r;
             return launch_reduce_batch(rjobs, s);
         }
         for (int l = L - 1; l >= 0; --l) {
@@ -1239,7 +1221,6 @@ extern "C" int shm_vae_backward(shm_vae_plan* p, const float* x, const float* d_
 
     kt_head.~KernelTimer(); kt_head.idx = -1;
     if ((rc = run_stack_bwd(p->enc, 0, x, false))) return rc;
-    if (pending.n > 0 && (rc = launch_reduce_batch(pending, s))) return rc;     // (the encoder stack ran without a pair launch)
     final_flush = use_side && !getenv("SHM_SP_TAIL_ON_SIDE");
     if ((rc = flush_deferred())) return rc;
     if (use_side) {                                          // join: everything after this call on s sees the complete gradient bucket

@@ -110,7 +110,6 @@ int launch_window_gather(const float* series, long long n_rows, int D, const int
                          float clip_z, float* out, hipStream_t s);
 int reduce_jobs_add(ReduceJobs& j, const float* partial, int nparts, size_t n_out, size_t stride, float* out0, float* out1, int tr_M = 0);
 int launch_reduce_batch(ReduceJobs& jobs, hipStream_t s);
-int reduce_jobs_finalize(ReduceJobs& jobs);     // fills vec / first_block, returns the number of 256-thread blocks (launch_reduce_batch does it itself)
 int launch_gemm_tn_f32(const GemmTnArgs& a, hipStream_t s, ReduceJobs* defer = nullptr);
 size_t gemm_tn_partial_elems(int R, int M, int N);
 // out[n] = sum_r A[r*lda + n], written to out0 and (if non-null) out1; scratch: colsum_scratch_elems(R,N) floats
@@ -177,9 +176,7 @@ int launch_lstm_bwd_bf16(int H, const LstmBwdArgsB& a, hipStream_t s);      // r
 int launch_dx_gemm_bf16(int H, const LstmBwdArgsB& a, hipStream_t s);       // time-parallel part: dx_seq = dpre_seq . W_ih
 // both layers of a 2-layer stack in one launch: l1 = top layer (its dpre_seq is handed to l0 inside the launch), l0 forms
 // dx = dpre^1 W_ih^1 itself; the two dpre_seq / dpre_tsum buffers must be distinct
-// tail / tail_blocks (H = 128 only): a finalized reduction batch that the top-layer workgroups run once their recurrence is done — they finish
-// ~0.06 ms before the layer-0 workgroups (which also form dx), so the previous stack's split-K reductions cost no time of their own there
-struct LstmBwdPairArgsB { LstmBwdArgsB l1, l0; unsigned* sync; unsigned* sync_other; unsigned* err; int role_lds_off; int tail_blocks; ReduceJobs tail; };
+struct LstmBwdPairArgsB { LstmBwdArgsB l1, l0; unsigned* sync; unsigned* sync_other; unsigned* err; int role_lds_off; };
 int launch_lstm_bwd_pair_bf16(int H, const LstmBwdPairArgsB& p, hipStream_t s);
 
 struct GemmTnArgsB {

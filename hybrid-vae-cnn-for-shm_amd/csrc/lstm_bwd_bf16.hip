@@ -27,7 +27,6 @@
 // top layer's dpre rows: the dx sequence is never written to HBM, and the two recurrences overlap on 2 x 128 CUs.  Roles
 // come from a ticket, so a consumer only ever waits for a workgroup that is already running.
 #include "kernels.hpp"
-#include "reduce_batch.hpp"
 
 namespace shm {
 
@@ -424,25 +423,8 @@ __global__ void __launch_bounds__(4 * H) lstm_bwd_pair_bf16_kernel(LstmBwdPairAr
         p.sync_other[16 * (1 + tile)] = 0u;
         if (ticket == 0) p.sync_other[0] = 0u;
     }
-    if (producer) {
-        lstm_bwd_body<H, DHTOP, true>(p.l1, tile, sync + 16 * (1 + tile));
-        // The top layer's recurrence is done ~0.06 ms before layer 0's (which also forms dx): its workgroups reduce the PREVIOUS stack's
-        // split-K partials meanwhile (reduce_batch.hpp: same chains per output as the stand-alone launch it replaces).  Two 256-thread
-        // blocks per pass and workgroup; every thread takes part in every pass (uniform barriers).
-        if constexpr (H == 128) {
-            if (p.tail_blocks > 0) {
-                __syncthreads();                           // the recurrence's LDS is free
-                f32x4 (*red4)[8][32] = reinterpret_cast<f32x4 (*)[8][32]>(smem_b);                          // [2][8][32] x 16 B
-                float (*red)[8][32] = reinterpret_cast<float (*)[8][32]>(reinterpret_cast<char*>(smem_b) + 2 * 8 * 32 * 16);   // [2][8][32] x 4 B
-                const int half = (int)threadIdx.x >> 8, t256 = (int)threadIdx.x & 255;
-                for (int it = 0; it * 2 * tiles < p.tail_blocks; ++it) {
-                    const int vb = (it * tiles + tile) * 2 + half;
-                    reduce_batch_block(p.tail, vb, t256, vb < p.tail_blocks, red4[half], red[half]);
-                    __syncthreads();                       // red / red4 are reused by the next pass
-                }
-            }
-        }
-    } else lstm_bwd_fused_dx_body<H, DROP>(p.l0, p.l1, tile, sync + 16 * (1 + tile), (gu32*)p.err);
+    if (producer) lstm_bwd_body<H, DHTOP, true>(p.l1, tile, sync + 16 * (1 + tile));
+    else lstm_bwd_fused_dx_body<H, DROP>(p.l0, p.l1, tile, sync + 16 * (1 + tile), (gu32*)p.err);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -6,7 +6,6 @@
 //   colsum, pack_*      : bias gradients; MFMA fragment-order weight packing (layouts in kernels.hpp)
 // One wave per window row; reductions are wave shuffles in a fixed order (bitwise reproducible).
 #include "kernels.hpp"
-#include "reduce_batch.hpp"
 
 namespace shm {
 
@@ -664,11 +663,65 @@ __global__ void __launch_bounds__(256) reduce_partials_v4_kernel(const float* __
     }
 }
 
-// every deferred reduction of a backward stage in one launch: block -> (job, 128 | 32 outputs) through the prefix table (reduce_batch.hpp)
+// every deferred reduction of a backward stage in one launch: block -> (job, 32 outputs) through the prefix table
 __global__ void __launch_bounds__(256) reduce_batch_kernel(ReduceJobs jobs) {
-    __shared__ f32x4 red4[8][32];
     __shared__ float red[8][32];
-    reduce_batch_block(jobs, (int)blockIdx.x, (int)threadIdx.x, true, red4, red);
+    int j = 0;
+    while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.first_block[j + 1]) ++j;
+    const ReduceJob jb = jobs.job[j];
+    const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const float* __restrict__ partial = jb.partial;
+    const size_t n = jb.stride;
+    if (jb.vec) {
+        // 16 bytes per lane: a block covers 128 outputs, a partial row is read in 512-byte runs (the 4-byte form streamed the 67 MB of a
+        // split-K GEMM's partials at 3.9 TB/s); same summation order per output as below
+        __shared__ f32x4 red4[8][32];
+        const size_t i4 = ((size_t)(blockIdx.x - jobs.first_block[j]) * 32 + o) * 4;
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 s0 = z4, s1 = z4, s2 = z4, s3 = z4, s4 = z4, s5 = z4, s6 = z4, s7 = z4;
+        if (i4 < jb.n_out) {
+            auto ld = [&](int p) { return *reinterpret_cast<const f32x4*>(partial + (size_t)p * n + i4); };
+            int p = grp;
+            for (; p + 56 < jb.nparts; p += 64) {
+                s0 += ld(p); s1 += ld(p + 8); s2 += ld(p + 16); s3 += ld(p + 24);
+                s4 += ld(p + 32); s5 += ld(p + 40); s6 += ld(p + 48); s7 += ld(p + 56);
+            }
+            for (; p < jb.nparts; p += 8) s0 += ld(p);
+        }
+        red4[grp][o] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+        __syncthreads();
+        if (grp == 0 && i4 < jb.n_out) {
+            const f32x4 v = ((red4[0][o] + red4[1][o]) + (red4[2][o] + red4[3][o])) + ((red4[4][o] + red4[5][o]) + (red4[6][o] + red4[7][o]));
+            *reinterpret_cast<f32x4*>(jb.out0 + i4) = v;
+            if (jb.out1) *reinterpret_cast<f32x4*>(jb.out1 + i4) = v;
+        }
+        return;
+    }
+    const size_t i = (size_t)(blockIdx.x - jobs.first_block[j]) * 32 + o;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
+    if (i < jb.n_out) {
+        int p = grp;
+        for (; p + 56 < jb.nparts; p += 64) {
+            s0 += partial[(size_t)p * n + i];
+            s1 += partial[(size_t)(p + 8) * n + i];
+            s2 += partial[(size_t)(p + 16) * n + i];
+            s3 += partial[(size_t)(p + 24) * n + i];
+            s4 += partial[(size_t)(p + 32) * n + i];
+            s5 += partial[(size_t)(p + 40) * n + i];
+            s6 += partial[(size_t)(p + 48) * n + i];
+            s7 += partial[(size_t)(p + 56) * n + i];
+        }
+        for (; p < jb.nparts; p += 8) s0 += partial[(size_t)p * n + i];
+    }
+    red[grp][o] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+    __syncthreads();
+    if (grp == 0 && i < jb.n_out) {
+        const float v = ((red[0][o] + red[1][o]) + (red[2][o] + red[3][o])) + ((red[4][o] + red[5][o]) + (red[6][o] + red[7][o]));
+        size_t dst = i;
+        if (jb.tr_M > 0) { const size_t nn = i / jb.tr_M, mm = i - nn * jb.tr_M; dst = mm * (jb.n_out / jb.tr_M) + nn; }
+        jb.out0[dst] = v;
+        if (jb.out1) jb.out1[dst] = v;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ on-device windowing
@@ -990,8 +1043,8 @@ int reduce_jobs_add(ReduceJobs& j, const float* partial, int nparts, size_t n_ou
     r.partial = partial; r.nparts = nparts; r.n_out = (unsigned)n_out; r.stride = stride; r.out0 = out0; r.out1 = out1; r.tr_M = tr_M;
     return SHM_OK;
 }
-// vec flags and the block prefix table of a batch; returns its block count
-int reduce_jobs_finalize(ReduceJobs& jobs) {
+int launch_reduce_batch(ReduceJobs& jobs, hipStream_t s) {
+    if (jobs.n == 0) return SHM_OK;
     int blocks = 0;
     for (int i = 0; i < jobs.n; ++i) {
         ReduceJob& r = jobs.job[i];
@@ -1001,11 +1054,6 @@ int reduce_jobs_finalize(ReduceJobs& jobs) {
         blocks += (int)((r.n_out + (r.vec ? 127 : 31)) / (r.vec ? 128 : 32));
     }
     jobs.first_block[jobs.n] = blocks;
-    return blocks;
-}
-int launch_reduce_batch(ReduceJobs& jobs, hipStream_t s) {
-    if (jobs.n == 0) return SHM_OK;
-    const int blocks = reduce_jobs_finalize(jobs);
     SHM_LAUNCH(reduce_batch_kernel, dim3(blocks), dim3(256), 0, s, jobs);
     SHM_LAUNCH_CHECK();
     jobs.n = 0;
